@@ -1,0 +1,8 @@
+"""MI355X-native early-exit document-classification inference path (drop-in for the reference's eval hot path).
+
+The directory name carries a hyphen, so import it with ``importlib.import_module("multi-modal-early-exit_amd")``
+(or ``import mmee_amd`` — a two-line alias module at the repo root).
+"""
+from . import config, synth  # noqa: F401
+from .config import (EarlyExitHead, EarlyExitInference, EarlyExitStrategy, ExitConfig, ModelConfig,  # noqa: F401
+                     POSSIBLE_EXITS, parse_exits)

@@ -1,0 +1,378 @@
+"""TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+CPU restatement (numpy float32 / float64) of the reference's early-exit evaluation path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import this module; the product path
+(``multi-modal-early-exit_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity pinning: the reference ships no tests / golden vectors for this path, its own EE forward
+cannot run on the installed transformers 5.x, and its arithmetic lives in the un-vendored
+third-party dependency ``transformers`` (reference pin ``^4.26.0``, pyproject.toml:24; container has 5.15.0).  This
+restatement is therefore pinned against outputs of the reference's own importable classes run here
+(``LayoutLMv3Exit``, ``max_confidence``, ``entropy`` from EE/models; ``Policy`` from EE/policy.py) composed with the
+installed HF ``LayoutLMv3Model`` — see ``tests/golden/make_golden.py`` (generator, runs only where /root/reference
+exists) and the committed ``tests/golden/*.npz`` it produced.
+
+Every function cites the reference lines it follows (``EE/...`` = /root/reference/EE/..., ``HF:`` = transformers
+models/layoutlmv3/modeling_layoutlmv3.py at 5.15.0).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+from scipy.special import erf as _erf
+
+F32 = np.float32
+EMBEDDING_EXITS = ("vision_avg", "text_avg", "text_visual_concat")
+_EMB_HEAD = {"vision_avg": "vision_exit_embeddings", "text_avg": "text_exit_embeddings",
+             "text_visual_concat": "concat_exit_embeddings"}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# small ops
+# ------------------------------------------------------------------------------------------------------------------
+def layer_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float) -> np.ndarray:
+    """torch.nn.LayerNorm over the last axis, float32 (biased variance)."""
+    x = x.astype(F32, copy=False)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps)) * g + b).astype(F32)
+
+
+def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray]) -> np.ndarray:
+    """torch.nn.Linear: x @ w.T + b, float32."""
+    y = x.astype(F32, copy=False) @ w.T
+    if b is not None:
+        y = y + b
+    return y.astype(F32, copy=False)
+
+
+def gelu(x: np.ndarray) -> np.ndarray:
+    """ACT2FN["gelu"] = exact erf GELU (HF:485-497)."""
+    x = x.astype(F32, copy=False)
+    return (x * F32(0.5) * (F32(1.0) + _erf(x * F32(1.0 / math.sqrt(2.0))).astype(F32))).astype(F32)
+
+
+def softmax64(x: np.ndarray, axis: int = -1) -> np.ndarray:
+    """scipy.special.softmax on float64 (EE/policy.py:30-32)."""
+    x = np.asarray(x, dtype=np.float64)
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A4: relative-position buckets                                                              HF:392-413
+# ------------------------------------------------------------------------------------------------------------------
+def relative_position_bucket(rel: np.ndarray, num_buckets: int, max_distance: int) -> np.ndarray:
+    """Bidirectional bucket of HF:392-413 in float32 with truncation to integer, exactly as torch evaluates it:
+    ``max_exact + (log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).to(long)``.
+    """
+    rel = np.asarray(rel, dtype=np.int64)
+    nb = num_buckets // 2
+    ret = (rel > 0).astype(np.int64) * nb
+    n = np.abs(rel)
+    max_exact = nb // 2
+    is_small = n < max_exact
+    nf = np.maximum(n, 1).astype(F32)  # log(0) only occurs on the is_small branch, whose value is discarded
+    v = np.log(nf / F32(max_exact)) / F32(math.log(max_distance / max_exact)) * F32(nb - max_exact)
+    val_if_large = max_exact + v.astype(F32).astype(np.int64)  # .to(torch.long) truncates toward zero
+    val_if_large = np.minimum(val_if_large, nb - 1)
+    return ret + np.where(is_small, n, val_if_large)
+
+
+def bucket_lut(max_delta: int, num_buckets: int, max_distance: int) -> np.ndarray:
+    """LUT over delta in [-max_delta, max_delta] -> bucket (uint8).  Index = delta + max_delta."""
+    d = np.arange(-max_delta, max_delta + 1, dtype=np.int64)
+    return relative_position_bucket(d, num_buckets, max_distance).astype(np.uint8)
+
+
+def visual_bbox(grid: int, max_len: int = 1000) -> np.ndarray:
+    """HF:575-596 ``create_visual_bbox``: cls box [1,1,999,999] then row-major patch boxes (integer trunc division)."""
+    xs = (np.arange(0, max_len * (grid + 1), max_len) // grid).astype(np.int64)
+    ys = xs.copy()
+    x0 = np.tile(xs[:-1], (grid, 1))
+    y0 = np.tile(ys[:-1], (grid, 1)).T
+    x1 = np.tile(xs[1:], (grid, 1))
+    y1 = np.tile(ys[1:], (grid, 1)).T
+    vb = np.stack([x0, y0, x1, y1], axis=-1).reshape(-1, 4)
+    return np.concatenate([np.array([[1, 1, max_len - 1, max_len - 1]], dtype=np.int64), vb], axis=0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# configuration helpers
+# ------------------------------------------------------------------------------------------------------------------
+def split_exits(exits: Sequence[Union[str, int]]) -> Tuple[List[str], List[int]]:
+    """Reference evaluation order: vision_avg, text_avg, text_visual_concat (EE/models/LayoutLMv3.py:465-605), then
+    encoder layers ascending (:181-248)."""
+    emb = [e for e in EMBEDDING_EXITS if e in exits]
+    enc = sorted(int(e) for e in exits if isinstance(e, (int, np.integer)))
+    return emb, enc
+
+
+def exit_head(x: np.ndarray, W: Dict[str, np.ndarray], name: str) -> np.ndarray:
+    """``LayoutLMv3Exit.forward`` (EE/models/LayoutLMv3.py:86-93) == HF classification head (HF:799-823) in eval mode:
+    out_proj(tanh(dense(x))) when the head has a ``dense`` layer, else out_proj(x)."""
+    if f"{name}.dense.weight" in W:
+        x = np.tanh(linear(x, W[f"{name}.dense.weight"], W[f"{name}.dense.bias"])).astype(F32)
+    return linear(x, W[f"{name}.out_proj.weight"], W[f"{name}.out_proj.bias"])
+
+
+def max_confidence(logits: np.ndarray) -> np.ndarray:
+    """EE/models/EE_modules.py:157-160 (float32 softmax over dim 1, max)."""
+    x = logits.astype(F32)
+    m = x.max(axis=1, keepdims=True)
+    e = np.exp(x - m, dtype=F32)
+    return (e / e.sum(axis=1, keepdims=True, dtype=F32)).max(axis=1).astype(F32)
+
+
+def entropy(logits: np.ndarray) -> np.ndarray:
+    """EE/models/EE_modules.py:149-154 — no max shift (overflows for large logits, replicated on purpose)."""
+    x = logits.astype(F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ex = np.exp(x, dtype=F32)
+        A = ex.sum(axis=1, dtype=F32)
+        B = (x * ex).sum(axis=1, dtype=F32)
+        return (np.log(A) - B / A).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the forward pass
+# ------------------------------------------------------------------------------------------------------------------
+def position_ids_from_input_ids(input_ids: np.ndarray, pad: int) -> np.ndarray:
+    """HF:138-146: cumsum(ids != pad) * (ids != pad) + pad."""
+    m = (input_ids != pad).astype(np.int64)
+    return np.cumsum(m, axis=1) * m + pad
+
+
+def text_embeddings(cfg, W, input_ids, bbox, token_type_ids=None, position_ids=None) -> np.ndarray:
+    """A2 — HF:160-199 (+ HF:112-136 spatial concat), LayerNorm eps = layer_norm_eps."""
+    p = "layoutlmv3.embeddings."
+    if position_ids is None:
+        position_ids = position_ids_from_input_ids(input_ids, cfg.pad_token_id)
+    if token_type_ids is None:
+        token_type_ids = np.zeros_like(input_ids)
+    e = W[p + "word_embeddings.weight"][input_ids] + W[p + "token_type_embeddings.weight"][token_type_ids]
+    e = e + W[p + "position_embeddings.weight"][position_ids]
+    X, Y = W[p + "x_position_embeddings.weight"], W[p + "y_position_embeddings.weight"]
+    Hh, Ww = W[p + "h_position_embeddings.weight"], W[p + "w_position_embeddings.weight"]
+    hi = cfg.max_2d_position_embeddings - 1
+    sp = np.concatenate([
+        X[bbox[..., 0]], Y[bbox[..., 1]], X[bbox[..., 2]], Y[bbox[..., 3]],
+        Hh[np.clip(bbox[..., 3] - bbox[..., 1], 0, hi)], Ww[np.clip(bbox[..., 2] - bbox[..., 0], 0, hi)]], axis=-1)
+    e = (e + sp).astype(F32)
+    return layer_norm(e, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], cfg.layer_norm_eps)
+
+
+def image_embeddings(cfg, W, pixel_values) -> np.ndarray:
+    """A1 — ``forward_image`` (EE/models/LayoutLMv3.py:358-373; HF:71-83, 603-618): Conv2d(k=s=patch) as a GEMM over
+    (c, ky, kx); prepend cls_token; + pos_embed; LayerNorm eps 1e-6."""
+    p = "layoutlmv3."
+    B, C, R, _ = pixel_values.shape
+    P, g = cfg.patch_size, cfg.input_size // cfg.patch_size
+    x = pixel_values.astype(F32).reshape(B, C, g, P, g, P).transpose(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P)
+    wt = W[p + "patch_embed.proj.weight"].reshape(cfg.hidden_size, C * P * P)
+    pe = linear(x, wt, W[p + "patch_embed.proj.bias"])
+    cls = np.broadcast_to(W[p + "cls_token"].reshape(1, 1, -1), (B, 1, cfg.hidden_size))
+    e = np.concatenate([cls, pe], axis=1) + W[p + "pos_embed"].reshape(1, -1, cfg.hidden_size)
+    return layer_norm(e.astype(F32), W[p + "norm.weight"], W[p + "norm.bias"], 1e-6)
+
+
+def attention_bias(cfg, W, position_ids: np.ndarray, bbox: np.ndarray) -> np.ndarray:
+    """A4 — ``_cal_1d_pos_emb`` + ``_cal_2d_pos_emb`` (HF:415-457; called at EE/models/LayoutLMv3.py:170-179):
+    rel[b,i,j] = p[j] - p[i]; 1D buckets (rel_pos_bins, max_rel_pos), 2D buckets on x0 and on y1 (!); tables are the
+    transposed nn.Linear weights.  Returns rel_pos + rel_2d_pos, shape (B, heads, S, S) float32."""
+    e = "layoutlmv3.encoder."
+    def one(coord, nb, md, table):
+        rel = coord[:, None, :] - coord[:, :, None]
+        bk = relative_position_bucket(rel, nb, md)
+        return W[e + table].T[bk].transpose(0, 3, 1, 2).astype(F32)
+    r1 = one(position_ids, cfg.rel_pos_bins, cfg.max_rel_pos, "rel_pos_bias.weight")
+    rx = one(bbox[:, :, 0], cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, "rel_pos_x_bias.weight")
+    ry = one(bbox[:, :, 3], cfg.rel_2d_pos_bins, cfg.max_rel_2d_pos, "rel_pos_y_bias.weight")
+    return (r1 + (rx + ry)).astype(F32)
+
+
+def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.ndarray) -> np.ndarray:
+    """E1-E3 — one ``LayoutLMv3Layer`` (HF:235-303, 343-368, 485-512)."""
+    q = f"layoutlmv3.encoder.layer.{l}."
+    B, S, H = x.shape
+    nh, d = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    def heads(t):
+        return t.reshape(B, S, nh, d).transpose(0, 2, 1, 3)
+    Q = heads(linear(x, W[q + "attention.self.query.weight"], W[q + "attention.self.query.bias"]))
+    K = heads(linear(x, W[q + "attention.self.key.weight"], W[q + "attention.self.key.bias"]))
+    V = heads(linear(x, W[q + "attention.self.value.weight"], W[q + "attention.self.value.bias"]))
+    sd = F32(math.sqrt(d))
+    s = (Q / sd) @ K.transpose(0, 1, 3, 2)                     # HF:263
+    s = s + bias / sd                                          # HF:265-268
+    s = (s + ext_mask).astype(F32)                             # HF:270-272
+    # CogView PB-relax softmax, HF:223-233
+    alpha = F32(32.0)
+    sc = s / alpha
+    mx = sc.max(axis=-1, keepdims=True)
+    z = (sc - mx) * alpha
+    ez = np.exp(z - z.max(axis=-1, keepdims=True), dtype=F32)
+    probs = (ez / ez.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    ctx = (probs @ V).transpose(0, 2, 1, 3).reshape(B, S, H)
+    a = linear(ctx, W[q + "attention.output.dense.weight"], W[q + "attention.output.dense.bias"])
+    a = layer_norm(a + x, W[q + "attention.output.LayerNorm.weight"], W[q + "attention.output.LayerNorm.bias"],
+                   cfg.layer_norm_eps)                          # HF:299-303
+    f = gelu(linear(a, W[q + "intermediate.dense.weight"], W[q + "intermediate.dense.bias"]))
+    f = linear(f, W[q + "output.dense.weight"], W[q + "output.dense.bias"])
+    return layer_norm(f + a, W[q + "output.LayerNorm.weight"], W[q + "output.LayerNorm.bias"], cfg.layer_norm_eps)
+
+
+def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exits: Sequence[Union[str, int]],
+                strategy: str = "ramp", criterion: str = "max_confidence", return_hidden_cls: bool = False,
+                max_layers: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """Full-depth forward with every exit evaluated, as the reference does at eval time
+    (``LayoutLMv3EEForSequenceClassification.forward`` EE/models/LayoutLMv3.py:696-749, 871-896 ->
+    ``LayoutLMv3ModelEE.forward`` :375-665 -> ``LayoutLMv3EncoderEE.forward`` :151-305).
+
+    Returns
+      exit_logits   (E, B, K or 2)  float32   exit_states[j][0]
+      exit_crit     (E, B)          float32   exit_states[j][1]   (criterion on the exit head's own logits)
+      gated_logits  (E, B, K)       float32   classifier(gate_inputs[j])  — gate strategy only (:764-792)
+      logits        (B, K)          float32   final classifier
+      final_crit    (B,)            float32   exit_criteria[-1] (:871-872)
+      logits_store  (E+1, B, K)     float64   what the harness keeps (EE/utils.py:160-193): gated_logits[j] for gates,
+                                              exit_states[j][0] for ramps, final logits last
+    """
+    p = "layoutlmv3."
+    ids, bbox, pix = batch["input_ids"], batch["bbox"], batch["pixel_values"]
+    am = batch.get("attention_mask")
+    B, T = ids.shape
+    if am is None:
+        am = np.ones((B, T), dtype=np.int64)
+    emb_exits, enc_exits = split_exits(exits)
+    crit_fn = max_confidence if criterion == "max_confidence" else entropy
+    ex_logits: List[np.ndarray] = []
+    gate_inputs: List[np.ndarray] = []
+
+    vis = image_embeddings(cfg, W, pix)                                         # :445
+    Pv = vis.shape[1]
+    if "vision_avg" in emb_exits:                                               # :465-483
+        xin = vis.mean(axis=1, dtype=F32)
+        ex_logits.append(exit_head(xin, W, p + _EMB_HEAD["vision_avg"])); gate_inputs.append(xin)
+    txt = text_embeddings(cfg, W, ids, bbox, batch.get("token_type_ids"), batch.get("position_ids"))   # :511-517
+    if "text_avg" in emb_exits:                                                 # :519-534
+        xin = txt.mean(axis=1, dtype=F32)
+        ex_logits.append(exit_head(xin, W, p + _EMB_HEAD["text_avg"])); gate_inputs.append(xin)
+    x = np.concatenate([txt, vis], axis=1)                                      # :550
+    mask = np.concatenate([am, np.ones((B, Pv), dtype=np.int64)], axis=1)       # :553
+    g = cfg.input_size // cfg.patch_size
+    fb = np.concatenate([bbox, np.broadcast_to(visual_bbox(g)[None], (B, Pv, 4))], axis=1)            # :556
+    fpos = np.concatenate([np.broadcast_to(np.arange(T)[None], (B, T)),
+                           np.broadcast_to(np.arange(Pv)[None], (B, Pv))], axis=1)                    # :559-563
+    x = layer_norm(x, W[p + "LayerNorm.weight"], W[p + "LayerNorm.bias"], cfg.layer_norm_eps)         # :565
+    if "text_visual_concat" in emb_exits:                                       # :581-605 (mean over ALL positions)
+        xin = x.mean(axis=1, dtype=F32)
+        ex_logits.append(exit_head(xin, W, p + _EMB_HEAD["text_visual_concat"])); gate_inputs.append(xin)
+    ext = ((1.0 - mask[:, None, None, :].astype(F32)) * np.finfo(F32).min).astype(F32)                # :622-624
+    bias = attention_bias(cfg, W, fpos, fb)                                     # :170-179
+    cls_rows = [x[:, 0, :].copy()]
+    L = cfg.num_hidden_layers if max_layers is None else max_layers
+    k = 0
+    for l in range(L):                                                          # :181
+        x = encoder_layer(cfg, W, l, x, bias, ext)
+        cls_rows.append(x[:, 0, :].copy())
+        if (l + 1) in enc_exits:                                                # :222-248
+            xin = x[:, 0, :]
+            ex_logits.append(exit_head(xin, W, f"{p}encoder.early_exits.{k}")); gate_inputs.append(xin.copy())
+            k += 1
+    logits = exit_head(x[:, 0, :], W, "classifier")                             # :730-731
+    out: Dict[str, np.ndarray] = {"logits": logits, "final_crit": crit_fn(logits)}
+    E = len(ex_logits)
+    K = logits.shape[1]
+    if E:
+        out["exit_logits"] = np.stack(ex_logits)
+        out["exit_crit"] = np.stack([crit_fn(z) for z in ex_logits])
+    else:
+        out["exit_logits"] = np.zeros((0, B, K), F32); out["exit_crit"] = np.zeros((0, B), F32)
+    store = np.zeros((E + 1, B, K), dtype=np.float64)
+    if strategy == "gate":
+        gl = [exit_head(gi, W, "classifier") for gi in gate_inputs]             # :764-782
+        out["gated_logits"] = np.stack(gl) if gl else np.zeros((0, B, K), F32)
+        for j in range(E):
+            store[j] = gl[j]
+    else:
+        for j in range(E):
+            store[j] = ex_logits[j]
+    store[-1] = logits                                                          # EE/utils.py:193
+    out["logits_store"] = store
+    if return_hidden_cls:
+        out["hidden_cls"] = np.stack(cls_rows)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C2 / P1 / P2: temperature, policies
+# ------------------------------------------------------------------------------------------------------------------
+def temperature_scale(logits_store: np.ndarray, temperatures: Sequence[float]) -> np.ndarray:
+    """``TemperatureScaler.temperature_scale`` per exit (EE/generic_scaling.py:54-61 applied at EE/eval.py:321-323)."""
+    t = np.asarray(temperatures, dtype=np.float64).reshape(-1, 1, 1)
+    return np.asarray(logits_store, dtype=np.float64) / t
+
+
+def policy_scan(logits_store: np.ndarray, thresholds: Union[float, Sequence[float]]):
+    """Vectorised statement of the scan both policies share (EE/policy.py:28-45 / :87-104): first exit whose
+    max-softmax (float64) is STRICTLY greater than its threshold, else the last exit.
+    Returns (exits int32 (N,), predictions float64 (N,K), confidence float64 (N,))."""
+    L = np.asarray(logits_store, dtype=np.float64)
+    E1, N, K = L.shape
+    thr = np.broadcast_to(np.asarray(thresholds, dtype=np.float64).reshape(-1), (E1,)) if np.ndim(thresholds) else \
+        np.full((E1,), float(thresholds))
+    conf = softmax64(L, axis=-1).max(axis=-1)                 # (E1, N)
+    hit = conf > thr[:, None]
+    hit[-1, :] = True
+    ex = hit.argmax(axis=0).astype(np.int32)
+    idx = np.arange(N)
+    return ex, L[ex, idx, :], conf[ex, idx]
+
+
+def exit_distribution(exits: np.ndarray, num_exits_plus_1: int) -> Dict[int, float]:
+    """EE/policy.py:48-51."""
+    n = len(exits)
+    return {e: float(np.count_nonzero(exits == e)) / n for e in range(num_exits_plus_1)}
+
+
+def heuristic_thresholds(accuracy: Sequence[float], ece: Sequence[float], epsilon: float) -> np.ndarray:
+    """``accuracy_calibration_heuristic`` thresholds (EE/policy.py:68-79)."""
+    metrics = np.array([1 - (accuracy[i] / ece[i]) for i in range(len(accuracy))])
+    return (metrics - (metrics.min() - epsilon)) / ((metrics.max() + epsilon) - (metrics.min() - epsilon))
+
+
+def policy_loop(logits_store: np.ndarray, thresholds: Union[float, Sequence[float]]):
+    """Literal per-sample loop of EE/policy.py:28-45 (small N only) — checks ``policy_scan``."""
+    L = np.asarray(logits_store, dtype=np.float64)
+    E1, N, K = L.shape
+    thr = [float(thresholds)] * E1 if not np.ndim(thresholds) else [float(t) for t in thresholds]
+    ex = np.zeros(N, dtype=np.int32)
+    pred = np.zeros((N, K), dtype=np.float64)
+    for s in range(N):
+        for e in range(E1):
+            score = softmax64(L[e, s]).max()
+            if score > thr[e]:
+                ex[s] = e; pred[s] = L[e, s]
+                break
+            if e == E1 - 1:
+                ex[s] = e; pred[s] = L[e, s]
+    return ex, pred
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the early-exit contract the MI355X path returns: (logits, exit_layer, confidence)
+# ------------------------------------------------------------------------------------------------------------------
+def early_exit(cfg, W, batch, exits, thresholds, temperatures=None, strategy="ramp"):
+    """Simulated early exit == reference semantics: dump all exits (``forward_all``), optional per-exit temperature,
+    then the policy scan.  A document's decision only depends on its own prefix of exits (EE/policy.py:29-39), so
+    this equals a real compute-skipping exit."""
+    out = forward_all(cfg, W, batch, exits, strategy=strategy)
+    store = out["logits_store"]
+    if temperatures is not None:
+        store = temperature_scale(store, temperatures)
+    ex, pred, conf = policy_scan(store, thresholds)
+    return {"exit_layer": ex, "logits": pred, "confidence": conf, "logits_store": store}

@@ -1,0 +1,78 @@
+"""The oracle (oracle/ee_oracle.py) against the committed golden vectors minted from the composed reference
+(tests/golden/make_golden.py: HF encoder + the reference's own exit-head / criterion / Policy classes)."""
+import numpy as np
+import pytest
+
+from .conftest import BASE_EE, TINY_CASES, load_golden
+
+
+def test_bucket_lut_matches_hf(oracle):
+    g = load_golden("bucket_lut")
+    d = g["delta"]
+    assert np.array_equal(oracle.relative_position_bucket(d, 32, 128), g["lut_1d_32_128"])
+    assert np.array_equal(oracle.relative_position_bucket(d, 64, 256), g["lut_2d_64_256"])
+    assert np.array_equal(oracle.bucket_lut(1023, 32, 128), g["lut_1d_32_128"])
+
+
+@pytest.mark.parametrize("name", list(TINY_CASES))
+def test_tiny_forward_matches_reference(pkg, oracle, name):
+    g = load_golden(name)
+    ee = TINY_CASES[name]
+    cfg = pkg.ModelConfig.tiny(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    ec = cfg.exit_config
+    out = oracle.forward_all(cfg, W, docs, ec.exits, strategy=str(ec.encoder_layer_strategy),
+                             criterion=str(ec.inference_strategy), return_hidden_cls=True)
+    tol = dict(rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], **tol)
+    np.testing.assert_allclose(out["exit_logits"], g["exit_logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["exit_crit"], g["exit_crit"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["final_crit"], g["final_crit"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+    if "gated_logits" in g:
+        np.testing.assert_allclose(out["gated_logits"], g["gated_logits"], rtol=0, atol=1e-4)
+
+
+def test_tiny_policy_matches_reference(oracle):
+    g = load_golden("tiny_ramp")
+    for i in range(4):
+        ex, pred, conf = oracle.policy_scan(g["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex, g[f"pol_exits{i}"]) and ex.dtype == np.int32
+        np.testing.assert_array_equal(pred, g[f"pol_pred{i}"])
+        d = oracle.exit_distribution(ex, g["logits_store"].shape[0])
+        np.testing.assert_allclose([d[k] for k in sorted(d)], g[f"pol_dist{i}"])
+        ex2, pred2 = oracle.policy_loop(g["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex2, ex) and np.array_equal(pred2, pred)
+
+
+def test_policy_random_matches_reference(oracle):
+    g = load_golden("policy_random")
+    for i in range(5):
+        ex, pred, _ = oracle.policy_scan(g["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex, g[f"pol_exits{i}"])
+        np.testing.assert_array_equal(pred, g[f"pol_pred{i}"])
+    thr = oracle.heuristic_thresholds(g["heur_accuracy"], g["heur_ece"], float(g["heur_eps"]))
+    ex, pred, _ = oracle.policy_scan(g["logits_store"], thr)
+    assert np.array_equal(ex, g["heur_exits"])
+    np.testing.assert_array_equal(pred, g["heur_pred"])
+
+
+def test_base_shape_matches_reference(pkg, oracle):
+    """S = 709 (512 text + 197 visual), LayoutLMv3-base, 2 documents: CLS rows of every layer and all exit logits."""
+    from .conftest import load_golden as lg
+    import hashlib
+    g = lg("base_cls")
+    cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    assert sha(docs["pixel_values"]) == str(g["sha_pixel_values"]) and sha(docs["bbox"]) == str(g["sha_bbox"])
+    assert sha(W["layoutlmv3.embeddings.word_embeddings.weight"]) == str(g["sha_word_emb"])
+    out = oracle.forward_all(cfg, W, docs, BASE_EE["exits"], return_hidden_cls=True)
+    np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+    for i in range(4):
+        ex, pred, _ = oracle.policy_scan(out["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex, g[f"pol_exits{i}"])
