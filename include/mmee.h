@@ -1,0 +1,165 @@
+/*
+ * mmee.h — C-ABI of the MI355X-native early-exit document-classification path (libmmee_hip.so).
+ *
+ * The reference (Jordy-VL/multi-modal-early-exit) is pure Python and has no FFI layer; its boundary for this path is
+ * two Python call surfaces.  Each entry point below names the reference interface it replaces:
+ *
+ *   ee_create / ee_load_tensor / ee_finalize   <- configs.build_model -> LayoutLMv3EEForSequenceClassification
+ *                                                 .from_pretrained (EE/configs.py:389-411; model tree
+ *                                                 EE/models/LayoutLMv3.py:308-356, 669-694).  Tensors are addressed by
+ *                                                 their HF parameter names (EE/models/
+ *                                                 EELayoutLM_exit_named_parameters-wotherexits.json).
+ *   ee_forward                                  <- LayoutLMv3EEForSequenceClassification.forward
+ *                                                 (EE/models/LayoutLMv3.py:696-749, 871-896) + the harness loop
+ *                                                 utils.get_logits (EE/utils.py:169-193) + the early-exit decision of
+ *                                                 Policy.max_confidence_global_thresholding_policy /
+ *                                                 accuracy_calibration_heuristic (EE/policy.py:12-111) fused in,
+ *                                                 per-exit temperature of EE/generic_scaling.py:54-61 applied first.
+ *   ee_policy_scan                              <- Policy.* on a dumped (E+1, N, K) logits array (EE/policy.py:28-45,
+ *                                                 87-104; called from EE/eval.py:87-98).
+ *   ee_threshold_sweep                          <- thresh.opt1 / large_scale.opt0_2D vectorised exit-index search
+ *                                                 (EE/thresh.py:184-215, EE/large_scale.py:68-84).
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (message via ee_last_error).  All pointers
+ * marked "dev" are device (HBM) pointers borrowed from the caller for the duration of the enqueued work; kernels are
+ * enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream); no call synchronises with the host
+ * unless its comment says so.  One handle per device; a handle is not thread-safe.
+ */
+#ifndef MMEE_H
+#define MMEE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMEE_ABI_VERSION 1
+#define MMEE_MAX_ENCODER_EXITS 64
+
+/* embedding-level exits, in the order the reference evaluates them (EE/models/LayoutLMv3.py:465-605) */
+enum { MMEE_EXIT_VISION_AVG = 0, MMEE_EXIT_TEXT_AVG = 1, MMEE_EXIT_TEXT_VISUAL_CONCAT = 2 };
+/* encoder_layer_strategy (EE/models/EE_modules.py:167-172) */
+enum { MMEE_STRATEGY_RAMP = 0, MMEE_STRATEGY_GATE = 1 };
+/* inference_strategy (EE/models/EE_modules.py:116-146): max_confidence exits on crit > thr, entropy on crit < thr */
+enum { MMEE_CRIT_MAX_CONFIDENCE = 0, MMEE_CRIT_ENTROPY = 1 };
+/* arithmetic of the encoder GEMMs */
+enum { MMEE_PREC_F32 = 0, MMEE_PREC_BF16 = 1 };
+/* ee_load_tensor dtypes */
+enum { MMEE_DT_F32 = 0, MMEE_DT_F16 = 1, MMEE_DT_BF16 = 2 };
+/* ee_forward flags */
+enum {
+    MMEE_FLAG_DENSE_ROWS = 1,  /* keep all T text rows per document (pad rows computed, masked as keys) instead of the
+                                  ragged layout that drops pad rows; results are identical, this is the A/B switch  */
+    MMEE_FLAG_NO_EXIT = 2      /* dump-all mode: evaluate every exit for every document, nobody leaves early
+                                  (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
+};
+
+typedef struct ee_handle ee_handle;
+
+typedef struct ee_config {
+    int32_t abi_version;            /* MMEE_ABI_VERSION */
+    /* HF LayoutLMv3Config fields the path reads */
+    int32_t hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+    int32_t vocab_size, max_position_embeddings, type_vocab_size, pad_token_id;
+    int32_t max_2d_position_embeddings, coordinate_size, shape_size;
+    int32_t rel_pos_bins, max_rel_pos, rel_2d_pos_bins, max_rel_2d_pos;
+    int32_t input_size, patch_size, num_channels, num_labels;
+    float layer_norm_eps;
+    /* ExitConfig (EE/models/EE_modules.py:175-195) */
+    int32_t n_embedding_exits;                      /* 0..3 */
+    int32_t embedding_exits[3];                     /* MMEE_EXIT_*, evaluation order */
+    int32_t n_encoder_exits;
+    int32_t encoder_exit_layers[MMEE_MAX_ENCODER_EXITS];   /* 1-based, ascending; head k <-> encoder.early_exits.k */
+    int32_t exit_head_num_layers;                   /* 1 or 2 */
+    int32_t strategy;                               /* MMEE_STRATEGY_* */
+    int32_t criterion;                              /* MMEE_CRIT_* */
+    /* workspace sizing */
+    int32_t max_docs;                               /* largest B one ee_forward call may pass */
+    int32_t max_text_len;                           /* largest T */
+    int32_t precision;                              /* MMEE_PREC_* */
+} ee_config;
+
+int ee_create(const ee_config* cfg, ee_handle** out);
+int ee_destroy(ee_handle* h);
+const char* ee_last_error(const ee_handle* h);      /* h may be NULL: error of the last failed ee_create */
+
+/* Copy one parameter into the handle (the library owns its weight memory and may re-layout it).  `name` is the HF
+ * parameter name; `data` is a host pointer (is_device = 0) or a device pointer (is_device = 1) to a C-contiguous
+ * tensor of `dtype`; shape is checked against the config.  Unknown names are an error. */
+int ee_load_tensor(ee_handle* h, const char* name, const void* data, const int64_t* shape, int32_t ndim,
+                   int32_t dtype, int32_t is_device);
+/* Verify every parameter the config needs was loaded and build derived tables (relative-position value tables).
+ * Synchronises with the device. */
+int ee_finalize(ee_handle* h);
+/* Number of parameters the config expects / name of the i-th one (for loaders and tests). */
+int32_t ee_num_expected_tensors(const ee_handle* h);
+const char* ee_expected_tensor_name(const ee_handle* h, int32_t i);
+
+/*
+ * One pass of the hot path over a batch of B documents with T text tokens each.
+ *
+ *   input_ids      dev int64 (B,T)        attention_mask  dev int64 (B,T) or NULL (= ones)
+ *   bbox           dev int64 (B,T,4)      pixel_values    dev float (B,C,R,R)
+ *   token_type_ids dev int64 (B,T) or NULL (= zeros)      position_ids dev int64 (B,T) or NULL (= pad-aware cumsum)
+ *   thresholds     host double [E+1]: exit e leaves when sign(crit_e, thresholds[e]) (strict); entry E (final) unused
+ *   temperatures   host double [E+1] or NULL: logits of exit e are divided by temperatures[e] before the criterion
+ *                  and in every returned logit (calibrated logits, EE/eval.py:321-323)
+ * outputs (any may be NULL except out_exit):
+ *   out_logits     dev float  (B,K)   logits at the exit the document left through   ("predictions")
+ *   out_exit       dev int32  (B,)    index into the exit list, E = final classifier  ("exits_store")
+ *   out_conf       dev float  (B,)    criterion value at that exit
+ *   out_all_logits dev float  (E+1,B,K)  every evaluated exit's policy logits (ramp: exit_states[j][0]; gate:
+ *                  gated_logits[j]); rows of exits a document never reached are left untouched
+ *   out_all_crit   dev float  (E+1,B)    criterion of every evaluated exit on the policy logits
+ *   out_head_logits dev float (E,B,Kh)   raw exit-head logits (Kh = K for ramps, 2 for gates) = exit_states[j][0]
+ *   out_head_crit  dev float  (E,B)      criterion on the raw head logits = exit_states[j][1]
+ *   out_hidden_cls dev float  (L+1,B,H)  CLS row entering layer 0 and leaving every layer (debug / parity)
+ */
+int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
+               const float* pixel_values, const int64_t* token_type_ids, const int64_t* position_ids,
+               int32_t B, int32_t T, const double* thresholds, const double* temperatures, uint32_t flags,
+               float* out_logits, int32_t* out_exit, float* out_conf, float* out_all_logits, float* out_all_crit,
+               float* out_head_logits, float* out_head_crit, float* out_hidden_cls, void* stream);
+
+/* Per-stage statistics of the last ee_forward (synchronises with `stream`): active documents and packed rows entering
+ * each of the E+1 exit stages.  n_stages_out receives E+1. */
+int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int32_t cap, int32_t* n_stages_out,
+                         void* stream);
+/* FLOPs (2*M*N*K counting) the GEMM and attention kernels of the last ee_forward executed (synchronises). */
+int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* stream);
+
+/*
+ * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]
+ * (global threshold: repeat it).  exits dev int32 (N,), predictions dev double (N,K), confidence dev double (N,) or
+ * NULL, counts dev int32 [E1] or NULL (documents per exit).  Strict '>' on float64 max-softmax, last exit fallback.
+ */
+int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const double* thresholds,
+                   int32_t* exits, double* predictions, double* confidence, int32_t* counts, void* stream);
+
+/*
+ * Many threshold vectors at once over precomputed confidences (EE/thresh.py:184-215 / EE/large_scale.py:68-84
+ * semantics: exit = argmax_e(conf[e,n] >= thr[v,e]), i.e. first exit whose confidence reaches its threshold, 0 when
+ * none does).  conf dev float (E1,N), correct dev uint8 (E1,N) (1 = exit e classifies doc n correctly),
+ * thr dev float (V,E1).  Outputs dev: acc double (V,), mean_exit double (V,), exit_hist int32 (V,E1) or NULL.
+ */
+int ee_threshold_sweep(const float* conf, const uint8_t* correct, int32_t E1, int32_t N, const float* thr, int32_t V,
+                       double* acc, double* mean_exit, int32_t* exit_hist, void* stream);
+
+/* Per-kernel timing of subsequent ee_forward calls with HIP events recorded on the launch stream (adds two event
+ * records per launch; keep it off in timed runs).  ee_profile(h, 1) arms it and clears old records; every ee_forward
+ * replaces the records.  ee_profile_read synchronises the device and returns, for kernel role idx = 0,1,..., the
+ * role name as "role|hip_kernel_symbol(s)", the summed milliseconds and the number of timed launches of the last
+ * ee_forward; it returns 2 when idx is past the last role. */
+int ee_profile(ee_handle* h, int32_t enable);
+int ee_profile_read(ee_handle* h, int32_t idx, char* name_out, int32_t name_cap, double* total_ms, int32_t* launches);
+
+/* Host-only helper (no GPU needed): the relative_position_bucket LUT (HF modeling_layoutlmv3.py:392-413) over
+ * delta in [-max_delta, max_delta]; out_host has 2*max_delta+1 entries, index = delta + max_delta.  Exposed so the LUT
+ * the kernels use can be pinned against the HF-generated golden table. */
+int ee_bucket_lut(int32_t num_buckets, int32_t max_distance, int32_t max_delta, uint8_t* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMEE_H */

@@ -6,3 +6,5 @@ The directory name carries a hyphen, so import it with ``importlib.import_module
 from . import config, synth  # noqa: F401
 from .config import (EarlyExitHead, EarlyExitInference, EarlyExitStrategy, ExitConfig, ModelConfig,  # noqa: F401
                      POSSIBLE_EXITS, parse_exits)
+from . import capi  # noqa: F401,E402
+from .engine import EarlyExitEngine, EngineOutput, load_checkpoint_tensors, save_checkpoint  # noqa: F401,E402

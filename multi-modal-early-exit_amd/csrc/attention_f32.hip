@@ -1,0 +1,222 @@
+// Fused LayoutLMv3 self-attention (fp32 parity mode) on the CDNA4 matrix cores.
+//
+// Replaces LayoutLMv3SelfAttention.forward (HF:235-288) together with the materialised relative-position bias of
+// _cal_1d_pos_emb / _cal_2d_pos_emb (HF:415-457, called at EE/models/LayoutLMv3.py:170-179) and the additive mask of
+// get_extended_attention_mask (EE/models/LayoutLMv3.py:622-624):
+//
+//     scores = (Q/sqrt(d)) K^T + (rel_pos + rel_2d_pos)/sqrt(d) + mask ; probs = CogView-softmax(scores) ; ctx = probs V
+//
+// The reference writes two (B, heads, 709, 709) f32 bias tensors (48 MB per document) and re-reads them in every
+// layer, plus (B, heads, S, S) scores and probs.  Here nothing S x S ever reaches HBM:
+//   * the bias of a (query, key) pair is three LDS lookups into per-head VALUE tables indexed by
+//     pos_k - pos_q, x0_k - x0_q, y1_k - y1_q (bucket LUT composed with the nn.Linear tables and the 1/sqrt(d)
+//     scale once, at ee_finalize); the per-row (pos, x0, y1, key-valid) metadata rides along with the packed rows;
+//   * flash-style online softmax.  CogView's softmax((s/32 - max(s/32))*32) is the max-shifted softmax exactly
+//     (scaling by 32 is exact in binary floating point), so the running-max formulation differs only by rounding.
+//   * S^T = K Q^T is computed (keys on MFMA rows, queries on lanes) so every lane owns ONE query: row max / row sum
+//     are in-register reductions plus one exchange between the two lane halves; P^T is then directly the B operand
+//     of O^T = V^T P^T, whose accumulator again has the query on the lane (rescale = one multiply per register).
+//   * documents are ragged (pad rows are never materialised in the packed layout); a work item is
+//     (document, head, 128-query tile), persistent grid-stride, sizes read from device memory.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact f32).  Per 32-query x 32-key tile per wave: 32 MFMAs for S^T (d = 64),
+// 32 for O^T (two 32-wide halves of d) = 4096 matrix-pipe cycles, against ~50 LDS lookups + ~25 VALU per score.
+#include "mmee_common.h"
+
+namespace mmee {
+
+constexpr int QT = 128;        // queries per workgroup (4 waves x 32)
+constexpr int KT = 32;         // keys per tile
+constexpr int D = 64;          // head dim (base and large)
+constexpr int KSTR = 68;       // padded K row stride (floats): 16 lanes of a ds_read_b128 group on distinct slots
+constexpr int VSTR = 64;
+constexpr float kMasked = -3.0e38f;
+
+static __host__ __device__ inline size_t attn_lds_floats(int n1, int n2) {
+    return (size_t)2 * KT * KSTR + (size_t)2 * KT * VSTR + (size_t)2 * KT * 4 + (size_t)n1 + 2 * (size_t)n2;
+}
+size_t attention_f32_lds_bytes(const AttnArgs& a) { return attn_lds_floats(a.n1, a.n2) * sizeof(float); }
+
+__global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                                  // [2][KT][KSTR]
+    float* Vs = Ks + 2 * KT * KSTR;                    // [2][KT][VSTR]
+    RowMeta* Ms = reinterpret_cast<RowMeta*>(Vs + 2 * KT * VSTR);   // [2][KT]
+    float* T1 = reinterpret_cast<float*>(Ms + 2 * KT);
+    float* TX = T1 + a.n1;
+    float* TY = TX + a.n2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n_docs = a.counts->n_docs;
+    const int qtiles = (a.max_len + QT - 1) / QT;
+    const int n_items = n_docs * a.heads * qtiles;
+    int cur_head = -1;
+
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int doc = item / (a.heads * qtiles);
+        const int rem = item - doc * (a.heads * qtiles);
+        const int head = rem / qtiles, qt = rem - head * qtiles;
+        const int off = a.doc_off[doc];
+        const int len = a.doc_off[doc + 1] - off;
+        const int q0 = qt * QT;
+        if (q0 >= len) continue;                       // uniform over the workgroup
+
+        __syncthreads();                               // previous item's LDS reads are done
+        if (head != cur_head) {                        // per-head value tables -> LDS
+            for (int i = tid; i < a.n1; i += 256) T1[i] = a.t1[(size_t)head * a.n1 + i];
+            for (int i = tid; i < a.n2; i += 256) {
+                TX[i] = a.tx[(size_t)head * a.n2 + i];
+                TY[i] = a.ty[(size_t)head * a.n2 + i];
+            }
+            cur_head = head;
+        }
+
+        const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
+        const bool wave_active = (q0 + wave * 32) < len;
+        const int qrow = off + (qi < len ? qi : len - 1);
+        // Q fragment: element c of group g is Q[q][8g + 4hh + c]
+        f32x4 qf[8];
+        {
+            const float* qp = a.qkv + (size_t)qrow * a.ld + head * D + 4 * hh;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qp + 8 * g);
+        }
+        const RowMeta mq = a.meta[qrow];
+
+        // staging: K tile and V tile are each 32 rows x 16 float4 = 512 float4 -> 2 per thread per operand
+        const int st_row = tid >> 4;                   // 0..15 (+16)
+        const int st_c4 = (tid & 15) * 4;
+        f32x4 rk[2], rv[2];
+        RowMeta rm;
+        auto load_tile = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kr = k0 + st_row + 16 * i;
+                if (kr < len) {
+                    const float* p = a.qkv + (size_t)(off + kr) * a.ld + a.H + head * D + st_c4;
+                    rk[i] = *reinterpret_cast<const f32x4*>(p);
+                    rv[i] = *reinterpret_cast<const f32x4*>(p + a.H);
+                } else {
+                    rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (tid < KT) {
+                const int kr = k0 + tid;
+                if (kr < len) rm = a.meta[off + kr];
+                else rm = RowMeta{0, 0, 0, 0};
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<f32x4*>(Ks + (buf * KT + st_row + 16 * i) * KSTR + st_c4) = rk[i];
+                *reinterpret_cast<f32x4*>(Vs + (buf * KT + st_row + 16 * i) * VSTR + st_c4) = rv[i];
+            }
+            if (tid < KT) Ms[buf * KT + tid] = rm;
+        };
+
+        float m_run = kMasked, l_run = 0.f;
+        f32x16 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+
+        const int n_kt = (len + KT - 1) / KT;
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const bool more = kt + 1 < n_kt;
+            if (more) load_tile((kt + 1) * KT);
+            const int buf = kt & 1;
+            if (wave_active) {
+                // ---- S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q registers) -------
+                f32x16 s;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+                const float* kb = Ks + (buf * KT + l31) * KSTR + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[g][c], s, 0, 0, 0);
+                }
+                // ---- bias, mask, online softmax.  register e <-> key (e&3) + 8*(e>>2) + 4*hh of the tile ---------
+                float tmax = kMasked;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const RowMeta mk = Ms[buf * KT + kl];
+                    const float b1 = T1[mk.pos - mq.pos + a.c1];
+                    const float bx = TX[mk.x0 - mq.x0 + a.c2];
+                    const float by = TY[mk.y1 - mq.y1 + a.c2];
+                    const float bias = b1 + (bx + by);              // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455
+                    const float v = (mk.flags & 1) ? (s[e] + bias) : kMasked;
+                    s[e] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run, tmax);
+                const float alpha = expf(m_run - m_new);
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = expf(s[e] - m_new);
+                    s[e] = p;
+                    psum += p;
+                }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                // ---- O^T += V^T P^T : A operand = V^T (lane row = d), B operand = P^T (lane col = query) ---------
+                const float* vb = Vs + (buf * KT + 4 * hh) * VSTR + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = (e & 3) + 8 * (e >> 2);
+                    const float v0 = vb[kl * VSTR];
+                    const float v1 = vb[kl * VSTR + 32];
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
+                }
+            }
+            if (more) store_tile((kt + 1) & 1);
+            __syncthreads();
+        }
+
+        if (wave_active) {
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);   // the two lane halves hold disjoint keys
+            const float inv = 1.0f / l_tot;
+            if (qi < len) {
+                float* op = a.ctx + (size_t)(off + qi) * a.ldc + head * D + 4 * hh;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
+                    f32x4 w0, w1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { w0[c] = o0[4 * q4 + c] * inv; w1[c] = o1[4 * q4 + c] * inv; }
+                    *reinterpret_cast<f32x4*>(op + 8 * q4) = w0;
+                    *reinterpret_cast<f32x4*>(op + 8 * q4 + 32) = w1;
+                }
+            }
+        }
+    }
+}
+
+void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = attention_f32_lds_bytes(a);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int qtiles = (a.max_len + QT - 1) / QT;
+    long items = (long)max_docs * a.heads * qtiles;
+    int grid = 2 * num_cus;
+    if (items < grid) grid = (int)items;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(grid), dim3(256), lds, s, a);
+}
+
+}  // namespace mmee

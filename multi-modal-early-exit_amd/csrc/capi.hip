@@ -1,0 +1,753 @@
+// C-ABI of libmmee_hip.so (include/mmee.h): handle, parameter registry, workspace, and the forward pass that chains
+// the HIP kernels.  Host code only enqueues: after an exit stage the number of surviving documents/rows lives in
+// device memory and every later kernel sizes itself from it (persistent grid-stride launches), so there is no
+// host-side control flow on the exit decision (the reference loops in Python, EE/policy.py:28-45).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mmee.h"
+#include "mmee_kernels.h"
+
+using namespace mmee;
+
+namespace {
+
+std::string g_create_error;
+
+struct Param {
+    float* ptr = nullptr;
+    std::vector<int64_t> shape;
+    bool loaded = false;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+
+struct LayerW {
+    float *qkv_w, *qkv_b, *ao_w, *ao_b, *ao_g, *ao_beta, *f1_w, *f1_b, *f2_w, *f2_b, *f_g, *f_beta;
+};
+struct HeadW {
+    float *dense_w = nullptr, *dense_b = nullptr, *out_w = nullptr, *out_b = nullptr;
+    int out_dim = 0;
+};
+
+}  // namespace
+
+struct ee_handle {
+    ee_config cfg;
+    std::string err;
+    int num_cus = 256;
+    bool finalized = false;
+    std::map<std::string, Param> params;
+    std::vector<std::string> names;
+    std::vector<void*> allocs;
+    // model pointers
+    float *word, *type, *pos, *xtab, *ytab, *htab, *wtab, *emb_g, *emb_b;
+    float *patch_w, *patch_b, *cls_token, *pos_embed, *norm_g, *norm_b, *ln_g, *ln_b;
+    float *rel1, *relx, *rely;
+    std::vector<LayerW> layers;
+    HeadW emb_heads[3];
+    std::vector<HeadW> enc_heads;
+    HeadW classifier;
+    // derived
+    float *t1 = nullptr, *tx = nullptr, *ty = nullptr;
+    int n1 = 0, c1 = 0, n2 = 0, c2 = 0;
+    // workspace
+    float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
+    int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
+    RowMeta* meta[2];
+    int *doc_orig, *doc_off, *x_src, *meta_src;   // [(E+2)][max_docs+1]
+    StageCounts* counts;                          // [(E+2)]
+    double* thr_dev = nullptr;                    // scratch for ee_policy_scan
+    // optional per-kernel event timing (ee_profile)
+    bool prof_on = false;
+    struct ProfRec { int id; hipEvent_t a, b; double flops; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    size_t prof_used = 0;
+    // bookkeeping of the last forward
+    int last_B = 0, last_T = 0, last_stages = 0;
+    std::vector<int> layer_stage;
+    std::vector<int> exit_stage;
+    uint32_t last_flags = 0;
+};
+
+namespace {
+
+int fail(ee_handle* h, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return 1;
+}
+
+#define HIP_OK(h, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(h, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+template <typename T>
+int dev_alloc(ee_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
+    if (e != hipSuccess) return fail(h, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+int add_param(ee_handle* h, const std::string& name, float** slot, std::vector<int64_t> shape, float* into = nullptr) {
+    Param p;
+    p.shape = shape;
+    if (into) p.ptr = into;
+    else if (dev_alloc(h, &p.ptr, p.numel())) return 1;
+    if (slot) *slot = p.ptr;
+    h->params[name] = p;
+    h->names.push_back(name);
+    return 0;
+}
+
+int add_head(ee_handle* h, const std::string& name, HeadW* hw, int H, int out_dim, bool two) {
+    hw->out_dim = out_dim;
+    if (two) {
+        if (add_param(h, name + ".dense.weight", &hw->dense_w, {H, H})) return 1;
+        if (add_param(h, name + ".dense.bias", &hw->dense_b, {H})) return 1;
+    }
+    if (add_param(h, name + ".out_proj.weight", &hw->out_w, {out_dim, H})) return 1;
+    if (add_param(h, name + ".out_proj.bias", &hw->out_b, {out_dim})) return 1;
+    return 0;
+}
+
+// HF relative_position_bucket (HF:392-413) as a LUT over delta in [-max_delta, max_delta].  torch evaluates the log
+// branch in float32 and truncates; the only integers whose float32 value sits on a bucket edge are the exact edges
+// max_exact * 2^(k/ratio), where float32 lands on the integer itself — floor(t + 1e-6) in double reproduces that
+// (pinned against the HF-generated LUT in tests/golden/bucket_lut.npz).
+void bucket_lut_host(int num_buckets, int max_distance, int max_delta, unsigned char* out) {
+    const int nb = num_buckets / 2, me = nb / 2;
+    for (int d = -max_delta; d <= max_delta; ++d) {
+        int ret = d > 0 ? nb : 0;
+        const int n = d < 0 ? -d : d;
+        int v;
+        if (n < me) v = n;
+        else {
+            const double t = std::log((double)n / me) / std::log((double)max_distance / me) * (nb - me);
+            v = me + (int)std::floor(t + 1e-6);
+            if (v > nb - 1) v = nb - 1;
+        }
+        out[d + max_delta] = (unsigned char)(ret + v);
+    }
+}
+
+// kernel roles reported by ee_profile_read; the HIP symbol each role launches is in the second column
+const char* const kProfNames[] = {
+    "prep|doc_prep_kernel+doc_scan_kernel+row_meta_kernel",
+    "embed_text|embed_text_kernel",
+    "gemm_patch|gemm_f32_kernel<0,1>",
+    "embed_visual|embed_visual_kernel+pool_finish_kernel",
+    "gemm_qkv|gemm_f32_kernel<0,0>",
+    "attention|attention_f32_kernel",
+    "gemm_attn_out|gemm_f32_kernel<2,0>",
+    "layernorm|ln_rows_kernel",
+    "gemm_ffn_up|gemm_f32_kernel<1,0>",
+    "gemm_ffn_down|gemm_f32_kernel<2,0>",
+    "exit_head|gemm_f32_kernel<3,0>+head_out_kernel",
+    "exit_decide|exit_decide_kernel",
+    "compact|compact_rows_kernel",
+    "gather_cls|gather_cls_kernel",
+};
+enum { P_PREP = 0, P_EMBT, P_GPATCH, P_EMBV, P_GQKV, P_ATTN, P_GAO, P_LN, P_GUP, P_GDOWN, P_HEAD, P_DECIDE, P_COMPACT, P_GCLS, P_COUNT };
+
+struct ProfScope {
+    ee_handle* h;
+    hipStream_t s;
+    hipEvent_t b = nullptr;
+    ProfScope(ee_handle* h_, int id, hipStream_t s_) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        if (h->prof_used == h->prof_pool.size()) {
+            hipEvent_t a, bb;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&bb);
+            h->prof_pool.push_back({a, bb});
+        }
+        auto& ev = h->prof_pool[h->prof_used++];
+        h->prof_recs.push_back({id, ev.first, ev.second, 0.0});
+        b = ev.second;
+        (void)hipEventRecord(ev.first, s);
+    }
+    ~ProfScope() {
+        if (b) (void)hipEventRecord(b, s);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ee_profile(ee_handle* h, int32_t enable) {
+    if (!h) return 1;
+    h->prof_on = enable != 0;
+    h->prof_recs.clear();
+    h->prof_used = 0;
+    return 0;
+}
+
+int ee_profile_read(ee_handle* h, int32_t idx, char* name_out, int32_t name_cap, double* total_ms, int32_t* launches) {
+    if (!h) return 1;
+    if (idx < 0 || idx >= P_COUNT) return 2;
+    (void)hipDeviceSynchronize();
+    double ms = 0.0;
+    int n = 0;
+    for (auto& r : h->prof_recs)
+        if (r.id == idx) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; ++n; }
+        }
+    if (name_out && name_cap > 0) {
+        strncpy(name_out, kProfNames[idx], name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    return 0;
+}
+
+int ee_bucket_lut(int32_t num_buckets, int32_t max_distance, int32_t max_delta, uint8_t* out_host) {
+    if (!out_host || num_buckets < 4 || num_buckets > 256 || max_delta < 0) return 1;
+    bucket_lut_host(num_buckets, max_distance, max_delta, out_host);
+    return 0;
+}
+
+const char* ee_last_error(const ee_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ee_create(const ee_config* c, ee_handle** out) {
+    if (!c || !out) return fail(nullptr, "ee_create: null argument");
+    if (c->abi_version != MMEE_ABI_VERSION) return fail(nullptr, "ee_create: abi_version %d != %d", c->abi_version, MMEE_ABI_VERSION);
+    const int H = c->hidden_size, I = c->intermediate_size, L = c->num_hidden_layers, K = c->num_labels;
+    if (H % 128 || I % 128 || H > 1024) return fail(nullptr, "hidden_size/intermediate_size must be multiples of 128, hidden_size <= 1024");
+    if (H % c->num_attention_heads || H / c->num_attention_heads != 64) return fail(nullptr, "head dim must be 64");
+    if (4 * c->coordinate_size + 2 * c->shape_size != H) return fail(nullptr, "4*coordinate_size + 2*shape_size != hidden_size");
+    if (c->input_size % c->patch_size || (c->num_channels * c->patch_size * c->patch_size) % 32 || c->patch_size % 4 || c->input_size % 4)
+        return fail(nullptr, "unsupported patch geometry");
+    if (K < 1 || K > 64) return fail(nullptr, "num_labels must be in [1,64]");
+    if (c->n_embedding_exits < 0 || c->n_embedding_exits > 3 || c->n_encoder_exits < 0 || c->n_encoder_exits > MMEE_MAX_ENCODER_EXITS)
+        return fail(nullptr, "bad exit counts");
+    for (int i = 0; i < c->n_encoder_exits; ++i) {
+        const int l = c->encoder_exit_layers[i];
+        if (l < 1 || l > L || (i && l <= c->encoder_exit_layers[i - 1])) return fail(nullptr, "encoder_exit_layers must be ascending in [1,L]");
+    }
+    if (c->max_docs < 1 || c->max_text_len < 1 || c->max_text_len > 1024) return fail(nullptr, "max_docs >= 1, 1 <= max_text_len <= 1024");
+    if (c->precision != MMEE_PREC_F32) return fail(nullptr, "precision %d not built (fp32 only in this build)", c->precision);
+    if (c->exit_head_num_layers != 1 && c->exit_head_num_layers != 2) return fail(nullptr, "exit_head_num_layers must be 1 or 2");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, "no HIP device: libmmee_hip needs an MI355X (there is no CPU fallback)");
+
+    ee_handle* h = new ee_handle();
+    h->cfg = *c;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
+
+    // ---- parameter registry (HF names) ------------------------------------------------------------------------
+    const std::string p = "layoutlmv3.";
+    int rc = 0;
+    rc |= add_param(h, p + "embeddings.word_embeddings.weight", &h->word, {c->vocab_size, H});
+    rc |= add_param(h, p + "embeddings.token_type_embeddings.weight", &h->type, {c->type_vocab_size, H});
+    rc |= add_param(h, p + "embeddings.position_embeddings.weight", &h->pos, {c->max_position_embeddings, H});
+    rc |= add_param(h, p + "embeddings.x_position_embeddings.weight", &h->xtab, {c->max_2d_position_embeddings, c->coordinate_size});
+    rc |= add_param(h, p + "embeddings.y_position_embeddings.weight", &h->ytab, {c->max_2d_position_embeddings, c->coordinate_size});
+    rc |= add_param(h, p + "embeddings.h_position_embeddings.weight", &h->htab, {c->max_2d_position_embeddings, c->shape_size});
+    rc |= add_param(h, p + "embeddings.w_position_embeddings.weight", &h->wtab, {c->max_2d_position_embeddings, c->shape_size});
+    rc |= add_param(h, p + "embeddings.LayerNorm.weight", &h->emb_g, {H});
+    rc |= add_param(h, p + "embeddings.LayerNorm.bias", &h->emb_b, {H});
+    rc |= add_param(h, p + "patch_embed.proj.weight", &h->patch_w, {H, c->num_channels, c->patch_size, c->patch_size});
+    rc |= add_param(h, p + "patch_embed.proj.bias", &h->patch_b, {H});
+    const int NP = (c->input_size / c->patch_size) * (c->input_size / c->patch_size);
+    rc |= add_param(h, p + "cls_token", &h->cls_token, {1, 1, H});
+    rc |= add_param(h, p + "pos_embed", &h->pos_embed, {1, NP + 1, H});
+    rc |= add_param(h, p + "norm.weight", &h->norm_g, {H});
+    rc |= add_param(h, p + "norm.bias", &h->norm_b, {H});
+    rc |= add_param(h, p + "LayerNorm.weight", &h->ln_g, {H});
+    rc |= add_param(h, p + "LayerNorm.bias", &h->ln_b, {H});
+    rc |= add_param(h, p + "encoder.rel_pos_bias.weight", &h->rel1, {c->num_attention_heads, c->rel_pos_bins});
+    rc |= add_param(h, p + "encoder.rel_pos_x_bias.weight", &h->relx, {c->num_attention_heads, c->rel_2d_pos_bins});
+    rc |= add_param(h, p + "encoder.rel_pos_y_bias.weight", &h->rely, {c->num_attention_heads, c->rel_2d_pos_bins});
+    h->layers.resize(L);
+    for (int l = 0; l < L && !rc; ++l) {
+        LayerW& w = h->layers[l];
+        const std::string q = p + "encoder.layer." + std::to_string(l) + ".";
+        rc |= dev_alloc(h, &w.qkv_w, (size_t)3 * H * H);
+        rc |= dev_alloc(h, &w.qkv_b, (size_t)3 * H);
+        if (rc) break;
+        const char* nm[3] = {"query", "key", "value"};
+        for (int t = 0; t < 3; ++t) {           // fused [3H][H] weight: Q rows, K rows, V rows
+            rc |= add_param(h, q + "attention.self." + nm[t] + ".weight", nullptr, {H, H}, w.qkv_w + (size_t)t * H * H);
+            rc |= add_param(h, q + "attention.self." + nm[t] + ".bias", nullptr, {H}, w.qkv_b + (size_t)t * H);
+        }
+        rc |= add_param(h, q + "attention.output.dense.weight", &w.ao_w, {H, H});
+        rc |= add_param(h, q + "attention.output.dense.bias", &w.ao_b, {H});
+        rc |= add_param(h, q + "attention.output.LayerNorm.weight", &w.ao_g, {H});
+        rc |= add_param(h, q + "attention.output.LayerNorm.bias", &w.ao_beta, {H});
+        rc |= add_param(h, q + "intermediate.dense.weight", &w.f1_w, {I, H});
+        rc |= add_param(h, q + "intermediate.dense.bias", &w.f1_b, {I});
+        rc |= add_param(h, q + "output.dense.weight", &w.f2_w, {H, I});
+        rc |= add_param(h, q + "output.dense.bias", &w.f2_b, {H});
+        rc |= add_param(h, q + "output.LayerNorm.weight", &w.f_g, {H});
+        rc |= add_param(h, q + "output.LayerNorm.bias", &w.f_beta, {H});
+    }
+    const bool two = c->exit_head_num_layers == 2;
+    const int out_dim = c->strategy == MMEE_STRATEGY_RAMP ? K : 2;     // EE/models/LayoutLMv3.py:83
+    const char* emb_nm[3] = {"vision_exit_embeddings", "text_exit_embeddings", "concat_exit_embeddings"};
+    for (int i = 0; i < c->n_embedding_exits && !rc; ++i) {
+        const int kind = c->embedding_exits[i];
+        if (kind < 0 || kind > 2) { rc = fail(nullptr, "bad embedding exit kind"); break; }
+        rc |= add_head(h, p + emb_nm[kind], &h->emb_heads[kind], H, out_dim, two);
+    }
+    h->enc_heads.resize(c->n_encoder_exits);
+    for (int k = 0; k < c->n_encoder_exits && !rc; ++k)
+        rc |= add_head(h, p + "encoder.early_exits." + std::to_string(k), &h->enc_heads[k], H, out_dim, two);
+    rc |= add_head(h, "classifier", &h->classifier, H, K, true);       // HF:799-823, always dense + out_proj
+
+    // ---- workspace --------------------------------------------------------------------------------------------
+    const size_t Bm = c->max_docs, Tm = c->max_text_len, Pv = NP + 1;
+    const size_t rows = Bm * (Tm + Pv);
+    const int E = c->n_embedding_exits + c->n_encoder_exits;
+    const size_t tch = (Tm + 31) / 32, vch = (Pv + 31) / 32;
+    if (!rc) {
+        rc |= dev_alloc(h, &h->X, rows * H);
+        rc |= dev_alloc(h, &h->Y, rows * H);
+        rc |= dev_alloc(h, &h->QKV, rows * 3 * H);
+        rc |= dev_alloc(h, &h->CTX, rows * H);
+        rc |= dev_alloc(h, &h->H1, rows * I);
+        rc |= dev_alloc(h, &h->vis_raw, Bm * NP * H);
+        rc |= dev_alloc(h, &h->text_part, Bm * tch * H);
+        rc |= dev_alloc(h, &h->vis_part, Bm * vch * H);
+        rc |= dev_alloc(h, &h->cat_part, Bm * (tch + vch) * H);
+        for (int k = 0; k < 3; ++k) rc |= dev_alloc(h, &h->pooled[k], Bm * H);
+        rc |= dev_alloc(h, &h->hid, Bm * H);
+        rc |= dev_alloc(h, &h->hid2, Bm * H);
+        rc |= dev_alloc(h, &h->head_logits, Bm * 64);
+        rc |= dev_alloc(h, &h->pol_logits, Bm * 64);
+        rc |= dev_alloc(h, &h->text_dst, Bm * Tm);
+        rc |= dev_alloc(h, &h->emb_pos, Bm * Tm);
+        rc |= dev_alloc(h, &h->ntext, Bm);
+        rc |= dev_alloc(h, &h->row_src, rows);
+        rc |= dev_alloc(h, &h->err_flag, 4);
+        rc |= dev_alloc(h, &h->meta[0], rows);
+        rc |= dev_alloc(h, &h->meta[1], rows);
+        const size_t st = (size_t)(E + 2) * (Bm + 1);
+        rc |= dev_alloc(h, &h->doc_orig, st);
+        rc |= dev_alloc(h, &h->doc_off, st);
+        rc |= dev_alloc(h, &h->x_src, st);
+        rc |= dev_alloc(h, &h->meta_src, st);
+        rc |= dev_alloc(h, &h->counts, (size_t)(E + 2));
+        rc |= dev_alloc(h, &h->thr_dev, 256);
+    }
+    if (rc) {
+        g_create_error = h->err.empty() ? g_create_error : h->err;
+        for (void* q : h->allocs) (void)hipFree(q);
+        delete h;
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+int ee_destroy(ee_handle* h) {
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (void* q : h->allocs) (void)hipFree(q);
+    delete h;
+    return 0;
+}
+
+int32_t ee_num_expected_tensors(const ee_handle* h) { return h ? (int32_t)h->names.size() : 0; }
+const char* ee_expected_tensor_name(const ee_handle* h, int32_t i) {
+    if (!h || i < 0 || i >= (int32_t)h->names.size()) return nullptr;
+    return h->names[i].c_str();
+}
+
+static inline float half_to_float(uint16_t v) {
+    const uint32_t s = (v >> 15) & 1, e = (v >> 10) & 31, m = v & 1023;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = s << 31;
+        else {
+            int ee = -1;
+            uint32_t mm = m;
+            do { ++ee; mm <<= 1; } while (!(mm & 1024));
+            u = (s << 31) | ((uint32_t)(127 - 15 - ee) << 23) | ((mm & 1023) << 13);
+        }
+    } else if (e == 31) u = (s << 31) | 0x7f800000u | (m << 13);
+    else u = (s << 31) | ((e + 112) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int ee_load_tensor(ee_handle* h, const char* name, const void* data, const int64_t* shape, int32_t ndim, int32_t dtype,
+                   int32_t is_device) {
+    if (!h || !name || !data || !shape) return fail(h, "ee_load_tensor: null argument");
+    auto it = h->params.find(name);
+    if (it == h->params.end()) return fail(h, "ee_load_tensor: unknown parameter '%s'", name);
+    Param& p = it->second;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    bool same = (size_t)ndim == p.shape.size();
+    for (int i = 0; same && i < ndim; ++i) same = shape[i] == p.shape[i];
+    if (!same) {
+        std::string want, got;
+        for (auto d : p.shape) want += std::to_string(d) + ",";
+        for (int i = 0; i < ndim; ++i) got += std::to_string(shape[i]) + ",";
+        return fail(h, "ee_load_tensor: '%s' has shape (%s) but the config expects (%s)", name, got.c_str(), want.c_str());
+    }
+    if (dtype == MMEE_DT_F32) {
+        HIP_OK(h, hipMemcpy(p.ptr, data, n * sizeof(float), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else if ((dtype == MMEE_DT_F16 || dtype == MMEE_DT_BF16) && !is_device) {
+        std::vector<float> tmp(n);
+        const uint16_t* s = static_cast<const uint16_t*>(data);
+        for (size_t i = 0; i < n; ++i) {
+            if (dtype == MMEE_DT_BF16) {
+                const uint32_t u = (uint32_t)s[i] << 16;
+                memcpy(&tmp[i], &u, 4);
+            } else tmp[i] = half_to_float(s[i]);
+        }
+        HIP_OK(h, hipMemcpy(p.ptr, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        return fail(h, "ee_load_tensor: dtype %d (device=%d) not supported; pass f32, or f16/bf16 from host memory", dtype, is_device);
+    }
+    p.loaded = true;
+    h->finalized = false;
+    return 0;
+}
+
+int ee_finalize(ee_handle* h) {
+    if (!h) return 1;
+    std::string missing;
+    int nmiss = 0;
+    for (auto& n : h->names)
+        if (!h->params[n].loaded) {
+            if (nmiss < 8) missing += n + " ";
+            ++nmiss;
+        }
+    if (nmiss) return fail(h, "ee_finalize: %d parameter(s) not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? "..." : "");
+    const ee_config& c = h->cfg;
+    const int NP = (c.input_size / c.patch_size) * (c.input_size / c.patch_size);
+    const int maxpos = std::max(c.max_text_len, NP + 1);
+    h->c1 = maxpos - 1;
+    h->n1 = 2 * maxpos - 1;
+    h->c2 = c.max_2d_position_embeddings - 1;
+    h->n2 = 2 * c.max_2d_position_embeddings - 1;
+    if (!h->t1) {
+        if (dev_alloc(h, &h->t1, (size_t)c.num_attention_heads * h->n1)) return 1;
+        if (dev_alloc(h, &h->tx, (size_t)c.num_attention_heads * h->n2)) return 1;
+        if (dev_alloc(h, &h->ty, (size_t)c.num_attention_heads * h->n2)) return 1;
+    }
+    std::vector<unsigned char> l1(h->n1), l2(h->n2);
+    bucket_lut_host(c.rel_pos_bins, c.max_rel_pos, h->c1, l1.data());
+    bucket_lut_host(c.rel_2d_pos_bins, c.max_rel_2d_pos, h->c2, l2.data());
+    unsigned char *d1 = nullptr, *d2 = nullptr;
+    HIP_OK(h, hipMalloc((void**)&d1, h->n1));
+    HIP_OK(h, hipMalloc((void**)&d2, h->n2));
+    HIP_OK(h, hipMemcpy(d1, l1.data(), h->n1, hipMemcpyHostToDevice));
+    HIP_OK(h, hipMemcpy(d2, l2.data(), h->n2, hipMemcpyHostToDevice));
+    launch_build_value_tables(h->rel1, h->relx, h->rely, d1, d2, c.num_attention_heads, c.rel_pos_bins, c.rel_2d_pos_bins,
+                              h->n1, h->n2, 1.0f / std::sqrt((float)(c.hidden_size / c.num_attention_heads)), h->t1, h->tx,
+                              h->ty, nullptr);
+    HIP_OK(h, hipDeviceSynchronize());
+    (void)hipFree(d1);
+    (void)hipFree(d2);
+    h->finalized = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
+               const float* pixel_values, const int64_t* token_type_ids, const int64_t* position_ids, int32_t B, int32_t T,
+               const double* thresholds, const double* temperatures, uint32_t flags, float* out_logits, int32_t* out_exit,
+               float* out_conf, float* out_all_logits, float* out_all_crit, float* out_head_logits, float* out_head_crit,
+               float* out_hidden_cls, void* stream) {
+    if (!h) return 1;
+    if (!h->finalized) return fail(h, "ee_forward: call ee_finalize after loading the parameters");
+    if (!input_ids || !bbox || !pixel_values || !out_exit) return fail(h, "ee_forward: input_ids, bbox, pixel_values and out_exit are required");
+    const ee_config& c = h->cfg;
+    if (B < 1 || B > c.max_docs) return fail(h, "ee_forward: B=%d outside [1, max_docs=%d]", B, c.max_docs);
+    if (T < 1 || T > c.max_text_len) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
+    const int E = c.n_embedding_exits + c.n_encoder_exits;
+    if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int H = c.hidden_size, I = c.intermediate_size, L = c.num_hidden_layers, K = c.num_labels;
+    const int G = c.input_size / c.patch_size, NP = G * G, Pv = NP + 1;
+    const int max_len = T + Pv;
+    const int max_rows = B * max_len;
+    const int cus = h->num_cus;
+    const size_t sstride = (size_t)c.max_docs + 1;
+    const int tch = (T + 31) / 32, vch = (Pv + 31) / 32;
+    const bool no_exit = flags & MMEE_FLAG_NO_EXIT;
+    const int head_dim_out = c.strategy == MMEE_STRATEGY_RAMP ? K : 2;
+
+    auto S_doc_orig = [&](int st) { return h->doc_orig + st * sstride; };
+    auto S_doc_off = [&](int st) { return h->doc_off + st * sstride; };
+    auto S_x_src = [&](int st) { return h->x_src + st * sstride; };
+    auto S_meta_src = [&](int st) { return h->meta_src + st * sstride; };
+
+    HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
+    if (h->prof_on) { h->prof_recs.clear(); h->prof_used = 0; }
+    bool need[3] = {false, false, false};
+    for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
+
+    // ---- stage 0: packed layout --------------------------------------------------------------------------------
+    PrepArgs pa{};
+    pa.input_ids = (const long long*)input_ids;
+    pa.attention_mask = (const long long*)attention_mask;
+    pa.bbox = (const long long*)bbox;
+    pa.position_ids = (const long long*)position_ids;
+    pa.B = B; pa.T = T; pa.Pv = Pv; pa.G = G;
+    pa.pad_id = c.pad_token_id; pa.vocab = c.vocab_size; pa.max_2d = c.max_2d_position_embeddings; pa.max_pos = c.max_position_embeddings;
+    pa.dense_rows = (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0;
+    pa.text_dst = h->text_dst; pa.emb_pos = h->emb_pos; pa.ntext = h->ntext;
+    pa.doc_off = S_doc_off(0); pa.x_src = S_x_src(0); pa.doc_orig = S_doc_orig(0);
+    pa.meta = h->meta[0]; pa.counts = h->counts; pa.err_flag = h->err_flag;
+    { ProfScope ps(h, P_PREP, s); launch_prep(pa, s); }
+
+    // ---- embeddings --------------------------------------------------------------------------------------------
+    EmbedArgs ea{};
+    ea.input_ids = pa.input_ids; ea.token_type_ids = (const long long*)token_type_ids; ea.bbox = pa.bbox;
+    ea.emb_pos = h->emb_pos; ea.text_dst = h->text_dst; ea.ntext = h->ntext; ea.doc_off = S_doc_off(0);
+    ea.B = B; ea.T = T; ea.Pv = Pv; ea.H = H; ea.cs = c.coordinate_size; ea.ss = c.shape_size; ea.max_2d = c.max_2d_position_embeddings;
+    ea.word = h->word; ea.type = h->type; ea.pos = h->pos; ea.xtab = h->xtab; ea.ytab = h->ytab; ea.htab = h->htab; ea.wtab = h->wtab;
+    ea.ln1_g = h->emb_g; ea.ln1_b = h->emb_b; ea.eps1 = c.layer_norm_eps;
+    ea.ln2_g = h->ln_g; ea.ln2_b = h->ln_b; ea.eps2 = c.layer_norm_eps;
+    ea.X = h->X;
+    ea.text_part = need[MMEE_EXIT_TEXT_AVG] ? h->text_part : nullptr;
+    ea.cat_part = need[MMEE_EXIT_TEXT_VISUAL_CONCAT] ? h->cat_part : nullptr;
+    ea.cat_chunks = tch + vch;
+    { ProfScope ps(h, P_EMBT, s); launch_embed_text(ea, s); }
+
+    GemmArgs pg{};
+    pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
+    pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
+    pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
+    { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
+
+    EmbedArgs va = ea;
+    va.ln1_g = h->norm_g; va.ln1_b = h->norm_b; va.eps1 = 1e-6f;        // layoutlmv3.norm = LayerNorm(eps=1e-6), HF:563
+    va.cls_token = h->cls_token; va.pos_embed = h->pos_embed; va.vis_raw = h->vis_raw;
+    va.vis_part = need[MMEE_EXIT_VISION_AVG] ? h->vis_part : nullptr;
+    {
+        ProfScope ps(h, P_EMBV, s);
+        launch_embed_visual(va, s);
+        if (need[MMEE_EXIT_VISION_AVG]) launch_pool_finish(h->vis_part, vch, H, (float)Pv, h->pooled[0], B, s);
+        if (need[MMEE_EXIT_TEXT_AVG]) launch_pool_finish(h->text_part, tch, H, (float)T, h->pooled[1], B, s);
+        if (need[MMEE_EXIT_TEXT_VISUAL_CONCAT]) launch_pool_finish(h->cat_part, tch + vch, H, (float)(T + Pv), h->pooled[2], B, s);
+    }
+
+    // ---- exit stages ---------------------------------------------------------------------------------------------
+    int cur = 0, meta_cur = 0, exit_index = 0;
+    const int* x_phys = S_x_src(0);
+    bool use_row_src = false;
+    h->layer_stage.assign(L, 0);
+    h->exit_stage.assign(E + 1, 0);
+
+    auto run_head = [&](const HeadW& hw, const float* in, int ld, const int* gather, float* hid, float* out) {
+        const int* n_docs_ptr = &h->counts[cur].n_docs;
+        const float* hin = in;
+        int hld = ld;
+        const int* hg = gather;
+        if (hw.dense_w) {
+            GemmArgs g{};
+            g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f;
+            launch_gemm_f32(g, EPI_TANH, AMODE_ROWS, B, cus, s);
+            hin = hid; hld = H; hg = nullptr;
+        }
+        HeadOutArgs ho{};
+        ho.in = hin; ho.ld = hld; ho.gather = hg; ho.W = hw.out_w; ho.b = hw.out_b; ho.H = H; ho.Ko = hw.out_dim;
+        ho.n_docs_ptr = n_docs_ptr; ho.out = out;
+        launch_head_out(ho, B, s);
+    };
+
+    auto run_exit = [&](const HeadW* hw, const float* in, int ld, const int* gather, bool is_final) {
+        const float* pol;
+        const float* head = nullptr;
+        int Kh = K;
+        ProfScope* hs = new ProfScope(h, P_HEAD, s);
+        if (is_final) {
+            run_head(h->classifier, in, ld, gather, h->hid, h->pol_logits);
+            pol = h->pol_logits;
+        } else if (c.strategy == MMEE_STRATEGY_GATE) {
+            run_head(*hw, in, ld, gather, h->hid, h->head_logits);            // 2-way gate logits (exit_states)
+            run_head(h->classifier, in, ld, gather, h->hid2, h->pol_logits);  // gated_logits, EE/models/LayoutLMv3.py:768
+            pol = h->pol_logits; head = h->head_logits; Kh = head_dim_out;
+        } else {
+            run_head(*hw, in, ld, gather, h->hid, h->head_logits);
+            pol = h->head_logits; head = h->head_logits; Kh = K;
+        }
+        delete hs;
+        DecideArgs d{};
+        d.pol_logits = pol; d.head_logits = head; d.K = K; d.Kh = Kh;
+        d.thr = thresholds ? thresholds[exit_index] : 0.0;
+        d.temp = temperatures ? temperatures[exit_index] : 1.0;
+        d.criterion = c.criterion; d.is_final = is_final ? 1 : 0; d.no_exit = no_exit ? 1 : 0; d.exit_index = exit_index; d.B = B;
+        d.counts = &h->counts[cur]; d.doc_orig = S_doc_orig(cur); d.doc_off = S_doc_off(cur); d.x_phys = x_phys;
+        d.n_counts = &h->counts[cur + 1]; d.n_doc_orig = S_doc_orig(cur + 1); d.n_doc_off = S_doc_off(cur + 1);
+        d.n_x_src = S_x_src(cur + 1); d.n_meta_src = S_meta_src(cur + 1);
+        d.out_logits = out_logits; d.out_exit = out_exit; d.out_conf = out_conf;
+        d.out_all_logits = out_all_logits; d.out_all_crit = out_all_crit;
+        d.out_head_logits = out_head_logits; d.out_head_crit = out_head_crit;
+        { ProfScope ps(h, P_DECIDE, s); launch_decide(d, s); }
+        h->exit_stage[exit_index] = cur;
+        if (!is_final) {
+            ProfScope ps(h, P_COMPACT, s);
+            launch_compact_rows(&h->counts[cur + 1], S_doc_off(cur + 1), S_x_src(cur + 1), S_meta_src(cur + 1),
+                                h->meta[meta_cur], h->meta[meta_cur ^ 1], h->row_src, B, cus, s);
+            meta_cur ^= 1;
+            cur += 1;
+            x_phys = S_x_src(cur);
+            use_row_src = true;
+        }
+        exit_index += 1;
+    };
+
+    for (int i = 0; i < c.n_embedding_exits; ++i) {
+        const int kind = c.embedding_exits[i];
+        run_exit(&h->emb_heads[kind], h->pooled[kind], H, S_doc_orig(cur), false);
+    }
+    if (out_hidden_cls)
+        launch_gather_cls(h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls, B, s);
+
+    int next_enc = 0;
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = h->layers[l];
+        const int* rows_ptr = &h->counts[cur].n_rows;
+        const int* rs = use_row_src ? h->row_src : nullptr;
+        h->layer_stage[l] = cur;
+        GemmArgs g{};
+        // QKV projection, Q pre-divided by sqrt(d) (HF:263)
+        g.A = h->X; g.lda = H; g.row_src = rs; g.W = w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
+        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f;
+        { ProfScope ps(h, P_GQKV, s); launch_gemm_f32(g, EPI_BIAS, AMODE_ROWS, max_rows, cus, s); }
+        AttnArgs at{};
+        at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
+        at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
+        at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len;
+        { ProfScope ps(h, P_ATTN, s); launch_attention_f32(at, B, cus, s); }
+        // attention output dense + residual (HF:299-303), then LayerNorm
+        g = GemmArgs{};
+        g.A = h->CTX; g.lda = H; g.W = w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
+        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f;
+        { ProfScope ps(h, P_GAO, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
+        // FFN (HF:485-512)
+        g = GemmArgs{};
+        g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f;
+        { ProfScope ps(h, P_GUP, s); launch_gemm_f32(g, EPI_GELU, AMODE_ROWS, max_rows, cus, s); }
+        g = GemmArgs{};
+        g.A = h->H1; g.lda = I; g.W = w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
+        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f;
+        { ProfScope ps(h, P_GDOWN, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
+        // the layer wrote X densely in the numbering of stage `cur`
+        x_phys = S_doc_off(cur);
+        use_row_src = false;
+        if (out_hidden_cls)
+            launch_gather_cls(h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs,
+                              out_hidden_cls + (size_t)(l + 1) * B * H, B, s);
+        if (next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1) {
+            run_exit(&h->enc_heads[next_enc], h->X, H, x_phys, false);
+            ++next_enc;
+        }
+    }
+    run_exit(nullptr, h->X, H, x_phys, true);
+    h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int32_t cap, int32_t* n_stages_out, void* stream) {
+    if (!h || !h->last_stages) return fail(h, "ee_last_stage_counts: no forward has run");
+    HIP_OK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<StageCounts> sc(h->last_stages);
+    HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * h->last_stages, hipMemcpyDeviceToHost));
+    int err = 0;
+    HIP_OK(h, hipMemcpy(&err, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_stages_out) *n_stages_out = h->last_stages;
+    for (int i = 0; i < h->last_stages && i < cap; ++i) {
+        if (docs_out) docs_out[i] = sc[h->exit_stage[i]].n_docs;
+        if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
+    }
+    if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id)", err);
+    return 0;
+}
+
+int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* stream) {
+    if (!h || !h->last_stages) return fail(h, "ee_last_flops: no forward has run");
+    HIP_OK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<StageCounts> sc(h->last_stages);
+    HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * h->last_stages, hipMemcpyDeviceToHost));
+    const ee_config& c = h->cfg;
+    const double H = c.hidden_size, I = c.intermediate_size;
+    const int G = c.input_size / c.patch_size;
+    double gf = 2.0 * h->last_B * G * G * (double)(c.num_channels * c.patch_size * c.patch_size) * H, af = 0.0;
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const StageCounts& s = sc[h->layer_stage[l]];
+        gf += 2.0 * s.n_rows * (4.0 * H * H + 2.0 * H * I);
+        af += 4.0 * (double)s.sum_len_sq * H;
+    }
+    const int E = h->last_stages - 1;
+    const double ko = c.strategy == MMEE_STRATEGY_RAMP ? c.num_labels : 2;
+    for (int e = 0; e <= E; ++e) {
+        const double n = sc[h->exit_stage[e]].n_docs;
+        const bool fin = e == E;
+        const double dense = (fin || c.exit_head_num_layers == 2) ? 2.0 * H * H : 0.0;
+        gf += n * (dense + 2.0 * H * (fin ? c.num_labels : ko));
+        if (!fin && c.strategy == MMEE_STRATEGY_GATE) gf += n * (2.0 * H * H + 2.0 * H * c.num_labels);
+    }
+    if (gemm_flops) *gemm_flops = gf;
+    if (attn_flops) *attn_flops = af;
+    return 0;
+}
+
+int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const double* thresholds, int32_t* exits,
+                   double* predictions, double* confidence, int32_t* counts, void* stream) {
+    if (!logits || !thresholds || !exits || E1 < 1 || E1 > 256 || N < 0 || K < 1) return fail(nullptr, "ee_policy_scan: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_policy_scan: no HIP device");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    double* thr_dev = nullptr;
+    if (hipMallocAsync((void**)&thr_dev, sizeof(double) * E1, s) != hipSuccess) return fail(nullptr, "ee_policy_scan: hipMallocAsync failed");
+    if (hipMemcpyAsync(thr_dev, thresholds, sizeof(double) * E1, hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(nullptr, "ee_policy_scan: threshold copy failed");
+    if (counts && hipMemsetAsync(counts, 0, sizeof(int) * E1, s) != hipSuccess) return fail(nullptr, "ee_policy_scan: memset failed");
+    if (N > 0) launch_policy_scan(logits, E1, N, K, thr_dev, exits, predictions, confidence, counts, s);
+    (void)hipFreeAsync(thr_dev, s);
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_policy_scan: launch failed");
+    return 0;
+}
+
+int ee_threshold_sweep(const float* conf, const uint8_t* correct, int32_t E1, int32_t N, const float* thr, int32_t V, double* acc,
+                       double* mean_exit, int32_t* exit_hist, void* stream) {
+    if (!conf || !correct || !thr || !acc || !mean_exit || E1 < 1 || E1 > 64 || N < 1 || V < 0)
+        return fail(nullptr, "ee_threshold_sweep: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_threshold_sweep: no HIP device");
+    if (V > 0) launch_threshold_sweep(conf, correct, E1, N, thr, V, acc, mean_exit, exit_hist, reinterpret_cast<hipStream_t>(stream));
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_threshold_sweep: launch failed");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// Exit heads' output projection, the on-device exit decision (confidence test -> wavefront ballot -> prefix sum ->
+// stream compaction of the document list), row-map expansion, and the policy / threshold-sweep kernels.
+//
+// What this replaces in the reference:
+//   * LayoutLMv3Exit.out_proj (EE/models/LayoutLMv3.py:92) / classifier.out_proj (HF:821) : head_out_kernel
+//   * max_confidence / entropy criteria (EE/models/EE_modules.py:149-160)                   : crit_f32 / crit_f64
+//   * Policy.max_confidence_global_thresholding_policy / accuracy_calibration_heuristic (EE/policy.py:28-45, 87-104):
+//     the nested Python loop "first exit whose float64 max-softmax is strictly above its threshold, else the last"
+//     becomes (a) exit_decide_kernel inside the forward pass — documents that satisfy the test are scattered to the
+//     outputs and removed, deeper layers run on the survivors only — and (b) policy_scan_kernel on a dumped
+//     (E+1,N,K) array, bit-identical in its integer outputs.
+//   * thresh.opt0_2D / large_scale.check_2D_threshold (EE/thresh.py:184-215, EE/large_scale.py:42-84): threshold_sweep.
+// All of it is HBM/latency-bound integer + small-vector work; none of it is shaped into a GEMM.
+#include "mmee_kernels.h"
+
+namespace mmee {
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[i][c] = <in[row(i)], W[c]> + b[c]; one wave per document
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs a) {
+    const int n = *a.n_docs_ptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const int row = a.gather ? a.gather[i] : i;
+        const float* x = a.in + (size_t)row * a.ld;
+        f32x4 xv[kMaxNV];
+#pragma unroll
+        for (int k = 0; k < kMaxNV; ++k) {
+            const int c = 4 * lane + 256 * k;
+            xv[k] = (c < a.H) ? *reinterpret_cast<const f32x4*>(x + c) : f32x4{0, 0, 0, 0};
+        }
+        for (int o = 0; o < a.Ko; ++o) {
+            const float* w = a.W + (size_t)o * a.H;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < kMaxNV; ++k) {
+                const int c = 4 * lane + 256 * k;
+                if (c < a.H) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+                    s += (xv[k][0] * wv[0] + xv[k][1] * wv[1]) + (xv[k][2] * wv[2] + xv[k][3] * wv[3]);
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) a.out[(size_t)i * a.Ko + o] = s + a.b[o];
+        }
+    }
+}
+
+void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s) {
+    int grid = (max_docs + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(head_out_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// criteria
+// ---------------------------------------------------------------------------------------------------------------
+// float32, as the model computes exit_states[j][1] (EE/models/EE_modules.py:149-160)
+__device__ inline float crit_f32(const float* z, int K, int criterion) {
+    if (criterion == 0) {
+        float m = z[0];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, z[k]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+        return 1.0f / s;
+    }
+    float A = 0.f, B = 0.f;                       // entropy: log(sum e^x) - sum(x e^x)/sum(e^x), no max shift
+    for (int k = 0; k < K; ++k) {
+        const float e = expf(z[k]);
+        A += e;
+        B += z[k] * e;
+    }
+    return logf(A) - B / A;
+}
+
+// float64 on (double)logit / T, as the policy computes it (scipy.special.softmax on the float64 store, EE/policy.py:30-32)
+__device__ inline double crit_f64(const float* z, int K, double temp, int criterion) {
+    if (criterion == 0) {
+        double m = (double)z[0] / temp;
+        for (int k = 1; k < K; ++k) m = fmax(m, (double)z[k] / temp);
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += exp((double)z[k] / temp - m);
+        return 1.0 / s;
+    }
+    double A = 0.0, B = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const double x = (double)z[k] / temp;
+        const double e = exp(x);
+        A += e;
+        B += x * e;
+    }
+    return log(A) - B / A;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The exit stage: one workgroup of 1024 threads walks the active documents in chunks of 1024.
+//   thread <-> document: criterion (f64), exit test, scatter of leavers to the output arrays;
+//   survivors: wave ballot -> popcount prefix -> cross-wave prefix in LDS -> running carry = new dense index,
+//   and the same scan over row counts = new dense row offset.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
+    __shared__ int s_cnt[16], s_rows[16];
+    __shared__ unsigned long long s_sq[16];
+    __shared__ int s_carry_docs, s_carry_rows;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.counts->n_docs;
+    if (tid == 0) { s_carry_docs = 0; s_carry_rows = 0; }
+    unsigned long long sq = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool active = i < n;
+        bool keep = false;
+        int len = 0, orig = 0;
+        if (active) {
+            orig = a.doc_orig[i];
+            len = a.doc_off[i + 1] - a.doc_off[i];
+            const float* z = a.pol_logits + (size_t)i * a.K;
+            const double crit = crit_f64(z, a.K, a.temp, a.criterion);
+            bool leave = a.criterion == 0 ? (crit > a.thr) : (crit < a.thr);   // strict, EE/policy.py:33
+            if (a.no_exit) leave = false;
+            if (a.is_final) leave = true;
+            if (a.out_all_logits) {
+                float* o = a.out_all_logits + ((size_t)a.exit_index * a.B + orig) * a.K;
+                for (int k = 0; k < a.K; ++k) o[k] = (float)((double)z[k] / a.temp);
+            }
+            if (a.out_all_crit) a.out_all_crit[(size_t)a.exit_index * a.B + orig] = (float)crit;
+            if (a.head_logits && a.out_head_logits) {
+                const float* hz = a.head_logits + (size_t)i * a.Kh;
+                float* o = a.out_head_logits + ((size_t)a.exit_index * a.B + orig) * a.Kh;
+                for (int k = 0; k < a.Kh; ++k) o[k] = hz[k];
+            }
+            if (a.head_logits && a.out_head_crit)
+                a.out_head_crit[(size_t)a.exit_index * a.B + orig] =
+                    crit_f32(a.head_logits + (size_t)i * a.Kh, a.Kh, a.criterion);
+            if (leave) {
+                if (a.out_logits)
+                    for (int k = 0; k < a.K; ++k) a.out_logits[(size_t)orig * a.K + k] = (float)((double)z[k] / a.temp);
+                a.out_exit[orig] = a.exit_index;
+                if (a.out_conf) a.out_conf[orig] = (float)crit;
+            }
+            keep = !leave;
+        }
+        // ---- wavefront ballot + prefix sums ------------------------------------------------------------------
+        const unsigned long long ballot = __ballot(keep);
+        const int before = __popcll(ballot & ((1ull << lane) - 1ull));       // survivors in lower lanes
+        const int klen = keep ? len : 0;
+        const int rows_incl = wave_incl_scan(klen, lane);
+        if (lane == 63) { s_cnt[wave] = __popcll(ballot); s_rows[wave] = rows_incl; }
+        if (keep) sq += (unsigned long long)len * (unsigned long long)len;
+        __syncthreads();
+        int wdocs = 0, wrows = 0, tdocs = 0, trows = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) { wdocs += s_cnt[w]; wrows += s_rows[w]; }
+            tdocs += s_cnt[w];
+            trows += s_rows[w];
+        }
+        const int cd = s_carry_docs, cr = s_carry_rows;
+        if (keep) {
+            const int k = cd + wdocs + before;
+            a.n_doc_orig[k] = orig;
+            a.n_doc_off[k] = cr + wrows + rows_incl - len;
+            a.n_x_src[k] = a.x_phys[i];
+            a.n_meta_src[k] = a.doc_off[i];
+        }
+        __syncthreads();
+        if (tid == 0) { s_carry_docs = cd + tdocs; s_carry_rows = cr + trows; }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (lane == 0) s_sq[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += s_sq[w];
+        a.n_doc_off[s_carry_docs] = s_carry_rows;
+        a.n_counts->n_docs = s_carry_docs;
+        a.n_counts->n_rows = s_carry_rows;
+        a.n_counts->sum_len_sq = t;
+    }
+}
+
+void launch_decide(const DecideArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(exit_decide_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
+// new dense row r of surviving document k  <-  physical X row n_x_src[k] + t, metadata row n_meta_src[k] + t
+__global__ __launch_bounds__(256) void compact_rows_kernel(const StageCounts* n_counts, const int* __restrict__ n_doc_off,
+                                                           const int* __restrict__ n_x_src, const int* __restrict__ n_meta_src,
+                                                           const RowMeta* __restrict__ meta_old, RowMeta* __restrict__ meta_new,
+                                                           int* __restrict__ row_src) {
+    const int n = n_counts->n_docs;
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const int off = n_doc_off[k], len = n_doc_off[k + 1] - off;
+        const int xs = n_x_src[k], ms = n_meta_src[k];
+        for (int t = threadIdx.x; t < len; t += 256) {
+            row_src[off + t] = xs + t;
+            meta_new[off + t] = meta_old[ms + t];
+        }
+    }
+}
+
+void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,
+                         const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s) {
+    int grid = max_docs < num_cus * 8 ? max_docs : num_cus * 8;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(grid), dim3(256), 0, s, n_counts, n_doc_off, n_x_src, n_meta_src,
+                       meta_old, meta_new, row_src);
+}
+
+// out[orig][:] = X[x_phys[i]][:]   (CLS rows, parity/debug output)
+__global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict__ X, int H, const int* __restrict__ x_phys,
+                                                         const int* __restrict__ doc_orig, const int* __restrict__ n_docs_ptr,
+                                                         float* __restrict__ out) {
+    const int n = *n_docs_ptr;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float* src = X + (size_t)x_phys[i] * H;
+        float* dst = out + (size_t)doc_orig[i] * H;
+        for (int c = threadIdx.x; c < H; c += 256) dst[c] = src[c];
+    }
+}
+
+void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr, float* out,
+                       int max_docs, hipStream_t s) {
+    int grid = max_docs < 2048 ? max_docs : 2048;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gather_cls_kernel, dim3(grid), dim3(256), 0, s, X, H, x_phys, doc_orig, n_docs_ptr, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Policy on a dumped (E1, N, K) float64 array: thread per document, scan exits in order.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void policy_scan_kernel(const double* __restrict__ logits, int E1, int N, int K,
+                                                          const double* __restrict__ thr, int* __restrict__ exits,
+                                                          double* __restrict__ pred, double* __restrict__ conf_out,
+                                                          int* __restrict__ counts) {
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        int chosen = E1 - 1;
+        double cchosen = 0.0;
+        for (int e = 0; e < E1; ++e) {
+            const double* z = logits + ((size_t)e * N + n) * K;
+            double m = z[0];
+            for (int k = 1; k < K; ++k) m = fmax(m, z[k]);
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s += exp(z[k] - m);
+            const double c = 1.0 / s;
+            cchosen = c;
+            if (c > thr[e]) { chosen = e; break; }
+        }
+        exits[n] = chosen;
+        if (conf_out) conf_out[n] = cchosen;
+        if (pred) {
+            const double* z = logits + ((size_t)chosen * N + n) * K;
+            for (int k = 0; k < K; ++k) pred[(size_t)n * K + k] = z[k];
+        }
+        if (counts) atomicAdd(&counts[chosen], 1);
+    }
+}
+
+void launch_policy_scan(const double* logits, int E1, int N, int K, const double* thr_dev, int* exits, double* pred,
+                        double* conf, int* counts, hipStream_t s) {
+    int grid = (N + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(policy_scan_kernel, dim3(grid), dim3(256), 0, s, logits, E1, N, K, thr_dev, exits, pred, conf, counts);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Threshold sweep: one workgroup per threshold vector, documents strided over its 256 threads.
+//   exit(v, n) = first e with conf[e][n] >= thr[v][e], else 0 (numpy argmax of an all-False column)
+// conf is (E1, N) so consecutive threads read consecutive documents of the same exit row (coalesced).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void threshold_sweep_kernel(const float* __restrict__ conf, const unsigned char* __restrict__ correct,
+                                                              int E1, int N, const float* __restrict__ thr, int V,
+                                                              double* __restrict__ acc, double* __restrict__ mean_exit,
+                                                              int* __restrict__ hist) {
+    __shared__ float s_thr[64];
+    __shared__ int s_hist[64];
+    __shared__ unsigned long long s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int v = blockIdx.x; v < V; v += gridDim.x) {
+        __syncthreads();
+        if (tid < E1) { s_thr[tid] = thr[(size_t)v * E1 + tid]; s_hist[tid] = 0; }
+        __syncthreads();
+        unsigned int n_correct = 0, sum_exit = 0;
+        for (int n = tid; n < N; n += 256) {
+            int ex = 0;
+            for (int e = 0; e < E1; ++e) {
+                if (conf[(size_t)e * N + n] >= s_thr[e]) { ex = e; break; }
+            }
+            n_correct += correct[(size_t)ex * N + n];
+            sum_exit += ex;
+            if (hist) atomicAdd(&s_hist[ex], 1);
+        }
+        unsigned long long packed = ((unsigned long long)n_correct << 32) | (unsigned long long)sum_exit;
+        for (int o = 32; o > 0; o >>= 1) packed += __shfl_xor(packed, o, 64);
+        if (lane == 0) s_red[wave] = packed;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+            acc[v] = (double)(t >> 32) / (double)N;
+            mean_exit[v] = (double)(t & 0xffffffffull) / (double)N;
+        }
+        if (hist && tid < E1) hist[(size_t)v * E1 + tid] = s_hist[tid];
+    }
+}
+
+void launch_threshold_sweep(const float* conf, const unsigned char* correct, int E1, int N, const float* thr, int V,
+                            double* acc, double* mean_exit, int* hist, hipStream_t s) {
+    int grid = V < 8192 ? V : 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(threshold_sweep_kernel, dim3(grid), dim3(256), 0, s, conf, correct, E1, N, thr, V, acc, mean_exit, hist);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// value tables of the relative-position bias: t[h][delta + c] = W[h][lut[delta + c]] / sqrt(d)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void build_value_tables_kernel(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,
+                                          const unsigned char* lut2, int heads, int bins1, int bins2, int n1, int n2,
+                                          float inv_sqrt_d, float* t1, float* tx, float* ty) {
+    const int h = blockIdx.x;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) t1[(size_t)h * n1 + i] = w1[(size_t)h * bins1 + lut1[i]] * inv_sqrt_d;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        tx[(size_t)h * n2 + i] = wx[(size_t)h * bins2 + lut2[i]] * inv_sqrt_d;
+        ty[(size_t)h * n2 + i] = wy[(size_t)h * bins2 + lut2[i]] * inv_sqrt_d;
+    }
+}
+
+void launch_build_value_tables(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,
+                               const unsigned char* lut2, int heads, int bins1, int bins2, int n1, int n2, float inv_sqrt_d,
+                               float* t1, float* tx, float* ty, hipStream_t s) {
+    hipLaunchKernelGGL(build_value_tables_kernel, dim3(heads), dim3(256), 0, s, w1, wx, wy, lut1, lut2, heads, bins1, bins2,
+                       n1, n2, inv_sqrt_d, t1, tx, ty);
+}
+
+}  // namespace mmee

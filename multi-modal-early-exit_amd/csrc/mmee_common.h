@@ -1,0 +1,138 @@
+// Internal declarations shared by the HIP translation units of libmmee_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmee {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Per-row metadata of the packed (ragged) sequence layout: what the in-kernel relative-position bias needs.
+//   pos   : position index used by the 1D bias = token index j for text rows, patch index v for visual rows
+//           (EE/models/LayoutLMv3.py:559-563 builds arange(T) ++ arange(197), NOT the pad-aware embedding positions)
+//   x0,y1 : bbox[...,0] and bbox[...,3] — the 2D bias buckets x0 and y1 (HF:433-434)
+//   flags : bit0 = row is a valid attention KEY (attention_mask != 0; visual rows always)
+struct RowMeta {
+    int pos, x0, y1, flags;
+};
+
+// Device-resident description of one exit stage (documents still active when the stage starts).
+struct StageCounts {
+    int n_docs;                    // active documents
+    int n_rows;                    // packed rows of the active documents
+    unsigned long long sum_len_sq; // sum over active documents of len^2 (attention FLOP accounting)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave helpers (wavefront = 64)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Row-wise LayerNorm on a row held by one wave: lane owns columns c = 4*lane + 256*i + e (i < NV, e < 4).
+// Two-pass (mean, then centred variance), biased variance, as torch.nn.LayerNorm.
+template <int NV>
+__device__ __forceinline__ void wave_layernorm(f32x4 (&x)[NV], int H, int lane, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = x[i][e] - mean;
+                v += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[i][e] = (x[i][e] - mean) * rstd * g[e] + b[e];
+        }
+    }
+}
+
+constexpr int kMaxNV = 4;  // hidden_size <= 1024, multiple of 4
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch parameter blocks
+// ---------------------------------------------------------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_TANH = 3 };
+enum { AMODE_ROWS = 0, AMODE_IM2COL = 1 };
+
+struct GemmArgs {
+    const float* A;
+    int lda;
+    const int* row_src;          // optional gather of A rows: A row of output row r is A[row_src[r]]
+    const float* W;              // [N][K] (torch Linear layout)
+    const float* bias;           // [N] or null
+    float* C;
+    int ldc;
+    const float* resid;          // EPI_RESID: C = acc + bias + resid[resid_row_src ? resid_row_src[r] : r]
+    int ldr;
+    const int* resid_row_src;
+    const int* m_ptr;            // device pointer to M (rows or docs of the active stage); null -> m_static
+    int m_static;
+    int N, K;
+    int scale_cols;              // columns [0, scale_cols) are multiplied by `scale` after the bias (Q / sqrt(d))
+    float scale;
+    // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
+    const float* pix;
+    int C_in, R, P, G;
+};
+
+struct AttnArgs {
+    const float* qkv;            // [rows][3H], Q already divided by sqrt(d)
+    int ld;
+    float* ctx;                  // [rows][H]
+    int ldc;
+    const RowMeta* meta;
+    const int* doc_off;          // [n_docs + 1] dense row offsets of the active stage
+    const StageCounts* counts;
+    const float* t1;             // [heads][n1]  rel_pos_bias[h][bucket1(delta)] / sqrt(d), index delta + c1
+    const float* tx;             // [heads][n2]  rel_pos_x_bias ...                          index delta + c2
+    const float* ty;             // [heads][n2]
+    int n1, c1, n2, c2;
+    int H, heads, max_len;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-side launchers (implemented next to their kernels)
+// ---------------------------------------------------------------------------------------------------------------
+void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_cus, hipStream_t s);
+void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
+size_t gemm_f32_lds_bytes();
+size_t attention_f32_lds_bytes(const AttnArgs& a);
+
+}  // namespace mmee

@@ -1,0 +1,107 @@
+// Parameter blocks + launchers of the row / exit kernels (prep_embed.hip, exit_ops.hip).
+#pragma once
+#include "mmee_common.h"
+
+namespace mmee {
+
+struct PrepArgs {
+    const long long* input_ids;      // (B,T)
+    const long long* attention_mask; // (B,T) or null
+    const long long* bbox;           // (B,T,4)
+    const long long* position_ids;   // (B,T) or null
+    int B, T, Pv, G;
+    int pad_id, vocab, max_2d, max_pos;
+    int dense_rows;
+    // outputs
+    int* text_dst;                   // (B,T) row index inside the document, -1 = dropped pad row
+    int* emb_pos;                    // (B,T) position id for the position-embedding lookup
+    int* ntext;                      // (B)   kept text rows
+    int* doc_off;                    // (B+1) stage-0 dense offsets
+    int* x_src;                      // (B)   physical offsets (= doc_off at stage 0)
+    int* doc_orig;                   // (B)
+    RowMeta* meta;
+    StageCounts* counts;
+    int* err_flag;                   // bit0 token id out of range, bit1 bbox out of range, bit2 position id out of range
+};
+
+struct EmbedArgs {
+    const long long* input_ids;
+    const long long* token_type_ids; // or null
+    const long long* bbox;
+    const int* emb_pos;
+    const int* text_dst;
+    const int* ntext;
+    const int* doc_off;
+    int B, T, Pv, H, cs, ss, max_2d;
+    const float *word, *type, *pos, *xtab, *ytab, *htab, *wtab;
+    const float *ln1_g, *ln1_b;      // text: embeddings.LayerNorm; visual: layoutlmv3.norm
+    float eps1;
+    const float *ln2_g, *ln2_b;      // layoutlmv3.LayerNorm
+    float eps2;
+    const float *cls_token, *pos_embed, *vis_raw;
+    float* X;
+    float* text_part;                // (B, ceil(T/32), H) or null
+    float* vis_part;                 // (B, ceil(Pv/32), H) or null
+    float* cat_part;                 // (B, cat_chunks, H) or null; text chunks first, then visual chunks
+    int cat_chunks;
+};
+
+struct HeadOutArgs {
+    const float* in;                 // rows of length H
+    int ld;
+    const int* gather;               // optional: input row of active doc i is in[gather[i]]
+    const float* W;                  // [Ko][H]
+    const float* b;                  // [Ko]
+    int H, Ko;
+    const int* n_docs_ptr;
+    float* out;                      // [n_docs][Ko]
+};
+
+struct DecideArgs {
+    const float* pol_logits;         // [n_docs][K]   logits the policy sees (ramp: head logits; gate: classifier(gate input))
+    const float* head_logits;        // [n_docs][Kh]  raw exit-head logits (== pol_logits for ramps); null for the final stage
+    int K, Kh;
+    double thr, temp;
+    int criterion, is_final, no_exit, exit_index, B;
+    // current stage
+    const StageCounts* counts;
+    const int* doc_orig;
+    const int* doc_off;              // dense offsets (n_docs + 1)
+    const int* x_phys;               // physical X offsets of the current stage's documents
+    // next stage
+    StageCounts* n_counts;
+    int* n_doc_orig;
+    int* n_doc_off;
+    int* n_x_src;
+    int* n_meta_src;
+    // outputs (original document numbering)
+    float* out_logits;               // (B,K)
+    int* out_exit;                   // (B)
+    float* out_conf;                 // (B)
+    float* out_all_logits;           // (E+1,B,K)
+    float* out_all_crit;             // (E+1,B)
+    float* out_head_logits;          // (E,B,Kh)
+    float* out_head_crit;            // (E,B)
+};
+
+void launch_prep(const PrepArgs& a, hipStream_t s);
+void launch_embed_text(const EmbedArgs& a, hipStream_t s);
+void launch_embed_visual(const EmbedArgs& a, hipStream_t s);
+void launch_pool_finish(const float* part, int chunks, int H, float count, float* pooled, int B, hipStream_t s);
+void launch_ln_rows(float* X, const int* n_rows_ptr, int max_rows, int H, const float* g, const float* b, float eps,
+                    int num_cus, hipStream_t s);
+void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s);
+void launch_decide(const DecideArgs& a, hipStream_t s);
+void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,
+                         const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s);
+void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr,
+                       float* out, int max_docs, hipStream_t s);
+void launch_policy_scan(const double* logits, int E1, int N, int K, const double* thr_dev, int* exits, double* pred,
+                        double* conf, int* counts, hipStream_t s);
+void launch_threshold_sweep(const float* conf, const unsigned char* correct, int E1, int N, const float* thr, int V,
+                            double* acc, double* mean_exit, int* hist, hipStream_t s);
+void launch_build_value_tables(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,
+                               const unsigned char* lut2, int heads, int bins1, int bins2, int n1, int n2, float inv_sqrt_d,
+                               float* t1, float* tx, float* ty, hipStream_t s);
+
+}  // namespace mmee

@@ -1,0 +1,382 @@
+// Document preparation, text / visual embedding rows, mean-pool exits' inputs and the row LayerNorm.
+//
+//   doc_prep / doc_scan / row_meta : the packed ("ragged") row layout.  A document contributes its valid text rows
+//       (attention_mask != 0; row 0 = CLS always) followed by its 197 visual rows.  Pad rows never enter the encoder:
+//       they are masked as keys (EE/models/LayoutLMv3.py:622-624) and no encoder-level exit reads them
+//       (:226 takes hidden[:,0,:]), so dropping them changes no observable output.  MMEE_FLAG_DENSE_ROWS keeps them.
+//   embed_text   : A2 = LayoutLMv3TextEmbeddings.forward (HF:160-199, spatial concat HF:112-136) + the model-level
+//                  LayerNorm of A3 (EE/models/LayoutLMv3.py:565); also the column sums for text_avg (:519-520) and
+//                  text_visual_concat (:581-582), which DO include pad rows.
+//   embed_visual : A1 tail = forward_image after the patch GEMM (EE/models/LayoutLMv3.py:358-373): prepend cls_token,
+//                  + pos_embed, LayerNorm eps 1e-6, then the model-level LayerNorm; column sums for vision_avg (:466).
+//   ln_rows      : LayerNorm of LayoutLMv3SelfOutput / LayoutLMv3Output (HF:299-303, 508-512) on packed rows.
+// All of these are HBM-bound row kernels: one wave per row, 16-byte vector loads, two-pass LayerNorm in registers.
+#include "mmee_common.h"
+#include "mmee_kernels.h"
+
+namespace mmee {
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void doc_prep_kernel(PrepArgs a) {
+    __shared__ int s_kept[256], s_np[256];
+    const int b = blockIdx.x, tid = threadIdx.x, T = a.T;
+    const int ept = (T + 255) / 256;
+    const int j0 = tid * ept;
+    int kept_cnt = 0, np_cnt = 0, bad = 0;
+    for (int e = 0; e < ept; ++e) {
+        const int j = j0 + e;
+        if (j < T) {
+            const long long id = a.input_ids[(size_t)b * T + j];
+            const bool valid = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0) : true;
+            kept_cnt += (a.dense_rows || valid || j == 0) ? 1 : 0;
+            np_cnt += (id != a.pad_id) ? 1 : 0;
+            bad |= (id < 0 || id >= a.vocab) ? 1 : 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long long v = a.bbox[((size_t)b * T + j) * 4 + c];
+                bad |= (v < 0 || v >= a.max_2d) ? 2 : 0;
+            }
+        }
+    }
+    s_kept[tid] = kept_cnt;
+    s_np[tid] = np_cnt;
+    __syncthreads();
+    // exclusive scan over 256 partial sums (tiny; serial per thread over LDS would be 256 reads — do a log-step scan)
+    for (int o = 1; o < 256; o <<= 1) {
+        const int vk = (tid >= o) ? s_kept[tid - o] : 0;
+        const int vn = (tid >= o) ? s_np[tid - o] : 0;
+        __syncthreads();
+        s_kept[tid] += vk;
+        s_np[tid] += vn;
+        __syncthreads();
+    }
+    int kbase = s_kept[tid] - kept_cnt, nbase = s_np[tid] - np_cnt;
+    for (int e = 0; e < ept; ++e) {
+        const int j = j0 + e;
+        if (j < T) {
+            const long long id = a.input_ids[(size_t)b * T + j];
+            const bool valid = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0) : true;
+            const bool kept = a.dense_rows || valid || j == 0;
+            a.text_dst[(size_t)b * T + j] = kept ? kbase : -1;
+            kbase += kept ? 1 : 0;
+            int pid;
+            if (a.position_ids) {
+                long long p = a.position_ids[(size_t)b * T + j];
+                if (p < 0 || p >= a.max_pos) { bad |= 4; p = 0; }
+                pid = (int)p;
+            } else {
+                // create_position_ids_from_input_ids (HF:138-146): cumsum(ids != pad) * (ids != pad) + pad
+                const int m = (id != a.pad_id) ? 1 : 0;
+                nbase += m;
+                pid = nbase * m + a.pad_id;
+                if (pid >= a.max_pos) { bad |= 4; pid = a.max_pos - 1; }
+            }
+            a.emb_pos[(size_t)b * T + j] = pid;
+        }
+    }
+    if (tid == 255) a.ntext[b] = s_kept[255];
+    if (bad) atomicOr(a.err_flag, bad);
+}
+
+// single workgroup: exclusive scan of document lengths -> stage 0 arrays
+__global__ __launch_bounds__(1024) void doc_scan_kernel(PrepArgs a) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    __shared__ unsigned long long s_sq[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    unsigned long long sq = 0;
+    __syncthreads();
+    for (int base = 0; base < a.B; base += 1024) {
+        const int i = base + tid;
+        const int len = (i < a.B) ? a.ntext[i] + a.Pv : 0;
+        sq += (unsigned long long)len * (unsigned long long)len;
+        const int inc = wave_incl_scan(len, lane);
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_w[w];
+        const int carry = s_carry;
+        if (i < a.B) {
+            const int off = carry + wbase + inc - len;
+            a.doc_off[i] = off;
+            a.x_src[i] = off;
+            a.doc_orig[i] = i;
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + wbase + inc;
+        __syncthreads();
+    }
+    // total len^2
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (lane == 0) s_sq[wave] = sq;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += s_sq[w];
+        a.doc_off[a.B] = s_carry;
+        a.counts->n_docs = a.B;
+        a.counts->n_rows = s_carry;
+        a.counts->sum_len_sq = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_meta_kernel(PrepArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, T = a.T;
+    const int off = a.doc_off[b];
+    const int nt = a.ntext[b];
+    const int hi = a.max_2d - 1;
+    for (int j = tid; j < T; j += 256) {
+        const int dst = a.text_dst[(size_t)b * T + j];
+        if (dst >= 0) {
+            RowMeta m;
+            m.pos = j;
+            long long x0 = a.bbox[((size_t)b * T + j) * 4 + 0], y1 = a.bbox[((size_t)b * T + j) * 4 + 3];
+            m.x0 = (int)(x0 < 0 ? 0 : (x0 > hi ? hi : x0));
+            m.y1 = (int)(y1 < 0 ? 0 : (y1 > hi ? hi : y1));
+            m.flags = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0 ? 1 : 0) : 1;
+            a.meta[off + dst] = m;
+        }
+    }
+    for (int v = tid; v < a.Pv; v += 256) {
+        RowMeta m;
+        m.pos = v;
+        if (v == 0) {                      // cls_token_box = [1, 1, max_len-1, max_len-1]  (HF:594)
+            m.x0 = 1;
+            m.y1 = 999;
+        } else {                           // create_visual_bbox (HF:575-596): trunc(1000*k / grid)
+            const int p = v - 1, py = p / a.G, px = p - py * a.G;
+            m.x0 = (1000 * px) / a.G;
+            m.y1 = (1000 * (py + 1)) / a.G;
+        }
+        m.flags = 1;
+        a.meta[off + nt + v] = m;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void wave_store_row(float* __restrict__ dst, const f32x4 (&x)[NV], int H, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) *reinterpret_cast<f32x4*>(dst + c) = x[i];
+    }
+}
+
+// reduce per-wave column sums of the 4 waves through LDS and write one partial row
+template <int NV>
+__device__ __forceinline__ void block_write_partial(float* lds, float* __restrict__ dst, const f32x4 (&acc)[NV],
+                                                    int H, int lane, int wave) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) *reinterpret_cast<f32x4*>(lds + wave * H + c) = acc[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) dst[c] = (lds[c] + lds[H + c]) + (lds[2 * H + c] + lds[3 * H + c]);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = a.T, H = a.H;
+    const int nch = (T + 31) / 32;
+    const int b = blockIdx.x / nch, ch = blockIdx.x - b * nch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cs = a.cs, ss = a.ss, hi = a.max_2d - 1;
+    const bool fast = ((cs & 3) == 0) && ((ss & 3) == 0);
+    f32x4 acc_t[NV], acc_c[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { acc_t[i] = f32x4{0, 0, 0, 0}; acc_c[i] = f32x4{0, 0, 0, 0}; }
+    const int doff = a.doc_off[b];
+    for (int t = 0; t < 8; ++t) {
+        const int j = ch * 32 + wave * 8 + t;
+        if (j >= T) break;                                    // wave-uniform
+        const size_t tok = (size_t)b * T + j;
+        const long long id = a.input_ids[tok];
+        const int tt = a.token_type_ids ? (int)a.token_type_ids[tok] : 0;
+        const int pid = a.emb_pos[tok];
+        int bb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            long long v = a.bbox[tok * 4 + c];
+            bb[c] = (int)(v < 0 ? 0 : (v > hi ? hi : v));
+        }
+        int hidx = bb[3] - bb[1]; hidx = hidx < 0 ? 0 : (hidx > hi ? hi : hidx);   // clip(y1 - y0, 0, 1023) HF:121
+        int widx = bb[2] - bb[0]; widx = widx < 0 ? 0 : (widx > hi ? hi : widx);   // clip(x1 - x0, 0, 1023) HF:122
+        f32x4 x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < H) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(a.word + (size_t)id * H + c);
+                v += *reinterpret_cast<const f32x4*>(a.type + (size_t)tt * H + c);
+                v += *reinterpret_cast<const f32x4*>(a.pos + (size_t)pid * H + c);
+                f32x4 sp;
+                if (fast) {
+                    const float* p;
+                    if (c < 4 * cs) {
+                        const int seg = c / cs, col = c - seg * cs;
+                        p = ((seg & 1) ? a.ytab : a.xtab) + (size_t)bb[seg] * cs + col;
+                    } else if (c < 4 * cs + ss) {
+                        p = a.htab + (size_t)hidx * ss + (c - 4 * cs);
+                    } else {
+                        p = a.wtab + (size_t)widx * ss + (c - 4 * cs - ss);
+                    }
+                    sp = *reinterpret_cast<const f32x4*>(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = c + e;
+                        float s;
+                        if (cc < 4 * cs) {
+                            const int seg = cc / cs, col = cc - seg * cs;
+                            s = ((seg & 1) ? a.ytab : a.xtab)[(size_t)bb[seg] * cs + col];
+                        } else if (cc < 4 * cs + ss) {
+                            s = a.htab[(size_t)hidx * ss + (cc - 4 * cs)];
+                        } else {
+                            s = a.wtab[(size_t)widx * ss + (cc - 4 * cs - ss)];
+                        }
+                        sp[e] = s;
+                    }
+                }
+                x[i] = v + sp;
+            } else {
+                x[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+        wave_layernorm<NV>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // embeddings.LayerNorm
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc_t[i] += x[i];
+        wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);      // layoutlmv3.LayerNorm (after the concat)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
+        const int dst = a.text_dst[tok];
+        if (dst >= 0) wave_store_row<NV>(a.X + (size_t)(doff + dst) * H, x, H, lane);
+    }
+    if (a.text_part) block_write_partial<NV>(lds, a.text_part + ((size_t)b * nch + ch) * H, acc_t, H, lane, wave);
+    if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + ch) * H, acc_c, H, lane, wave);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = a.H, Pv = a.Pv;
+    const int nch = (Pv + 31) / 32;
+    const int tch = (a.T + 31) / 32;
+    const int b = blockIdx.x / nch, ch = blockIdx.x - b * nch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc_v[NV], acc_c[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { acc_v[i] = f32x4{0, 0, 0, 0}; acc_c[i] = f32x4{0, 0, 0, 0}; }
+    const int doff = a.doc_off[b] + a.ntext[b];
+    for (int t = 0; t < 8; ++t) {
+        const int v = ch * 32 + wave * 8 + t;
+        if (v >= Pv) break;
+        f32x4 x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (c < H) {
+                f32x4 e = (v == 0) ? *reinterpret_cast<const f32x4*>(a.cls_token + c)
+                                   : *reinterpret_cast<const f32x4*>(a.vis_raw + ((size_t)b * (Pv - 1) + (v - 1)) * H + c);
+                x[i] = e + *reinterpret_cast<const f32x4*>(a.pos_embed + (size_t)v * H + c);
+            } else {
+                x[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+        wave_layernorm<NV>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // layoutlmv3.norm, eps 1e-6
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc_v[i] += x[i];
+        wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
+        wave_store_row<NV>(a.X + (size_t)(doff + v) * H, x, H, lane);
+    }
+    if (a.vis_part) block_write_partial<NV>(lds, a.vis_part + ((size_t)b * nch + ch) * H, acc_v, H, lane, wave);
+    if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + tch + ch) * H, acc_c, H, lane, wave);
+}
+
+// pooled[b][c] = (sum over chunks, in chunk order) / count      (x.mean(1), EE/models/LayoutLMv3.py:466, 520, 582)
+__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ part, int chunks, int H, float count,
+                                                          float* __restrict__ pooled) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < chunks; ++k) s += part[((size_t)b * chunks + k) * H + c];
+        pooled[(size_t)b * H + c] = s / count;
+    }
+}
+
+// in-place row LayerNorm over the packed rows of the active stage
+template <int NV>
+__global__ __launch_bounds__(256) void ln_rows_kernel(float* __restrict__ X, const int* __restrict__ n_rows_ptr, int H,
+                                                      const float* __restrict__ g, const float* __restrict__ b, float eps) {
+    const int n_rows = *n_rows_ptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
+        f32x4 x[NV];
+        float* p = X + (size_t)r * H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            x[i] = (c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
+        }
+        wave_layernorm<NV>(x, H, lane, g, b, eps);
+        wave_store_row<NV>(p, x, H, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+void launch_prep(const PrepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(doc_prep_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(doc_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(row_meta_kernel, dim3(a.B), dim3(256), 0, s, a);
+}
+
+void launch_embed_text(const EmbedArgs& a, hipStream_t s) {
+    const int grid = a.B * ((a.T + 31) / 32);
+    const size_t lds = 4 * (size_t)a.H * sizeof(float);
+    const int nv = (a.H + 255) / 256;
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(embed_text_kernel<1>, dim3(grid), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(embed_text_kernel<2>, dim3(grid), dim3(256), lds, s, a); break;
+        case 3: hipLaunchKernelGGL(embed_text_kernel<3>, dim3(grid), dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL(embed_text_kernel<4>, dim3(grid), dim3(256), lds, s, a); break;
+    }
+}
+
+void launch_embed_visual(const EmbedArgs& a, hipStream_t s) {
+    const int grid = a.B * ((a.Pv + 31) / 32);
+    const size_t lds = 4 * (size_t)a.H * sizeof(float);
+    const int nv = (a.H + 255) / 256;
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(embed_visual_kernel<1>, dim3(grid), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL(embed_visual_kernel<2>, dim3(grid), dim3(256), lds, s, a); break;
+        case 3: hipLaunchKernelGGL(embed_visual_kernel<3>, dim3(grid), dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL(embed_visual_kernel<4>, dim3(grid), dim3(256), lds, s, a); break;
+    }
+}
+
+void launch_pool_finish(const float* part, int chunks, int H, float count, float* pooled, int B, hipStream_t s) {
+    hipLaunchKernelGGL(pool_finish_kernel, dim3(B), dim3(256), 0, s, part, chunks, H, count, pooled);
+}
+
+void launch_ln_rows(float* X, const int* n_rows_ptr, int max_rows, int H, const float* g, const float* b, float eps,
+                    int num_cus, hipStream_t s) {
+    int grid = (max_rows + 3) / 4;
+    const int cap = num_cus * 8;
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    const int nv = (H + 255) / 256;
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
+        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
+        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
+        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
+    }
+}
+
+}  // namespace mmee

@@ -1,0 +1,288 @@
+"""Host-side driver of the HIP path: owns an ``ee_handle`` and moves pointers across the C-ABI.
+
+PyTorch is used for device memory (input / output tensors), streams and nothing else; all arithmetic of the path
+runs in libmmee_hip.so.  ``EarlyExitEngine.forward`` is the (logits, exit_layer, confidence) contract of the north
+star; ``LayoutLMv3EEForSequenceClassification`` (modeling.py) wraps it behind the reference's ``forward`` signature.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass
+from typing import Dict, Mapping, Optional, Sequence, Union
+
+import numpy as np
+
+from . import capi
+from .config import ModelConfig
+
+try:  # torch is plumbing (device tensors / streams); importing it must not be the reason the product "works"
+    import torch
+except Exception as _e:  # pragma: no cover
+    torch = None
+    _torch_err = _e
+
+
+@dataclass
+class EngineOutput:
+    logits: "torch.Tensor"                  # (B,K) float32 — logits at the exit each document left through
+    exit_layer: "torch.Tensor"              # (B,)  int32   — index into the exit list, E = final classifier
+    confidence: "torch.Tensor"              # (B,)  float32 — criterion at that exit
+    all_logits: Optional["torch.Tensor"] = None   # (E+1,B,K) policy logits of every evaluated exit (NaN = not reached)
+    all_crit: Optional["torch.Tensor"] = None     # (E+1,B)
+    head_logits: Optional["torch.Tensor"] = None  # (E,B,Kh) raw exit-head logits (exit_states[j][0])
+    head_crit: Optional["torch.Tensor"] = None    # (E,B)    (exit_states[j][1])
+    hidden_cls: Optional["torch.Tensor"] = None   # (L+1,B,H)
+
+
+def _require_torch_cuda(device=None):
+    if torch is None:
+        raise capi.MMEEUnavailable(f"PyTorch-ROCm is required for device tensors: {_torch_err}")
+    if not torch.cuda.is_available():
+        raise capi.MMEEUnavailable("no MI355X visible (torch.cuda.is_available() is False); the HIP path has no CPU fallback")
+    return torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+
+class EarlyExitEngine:
+    """One handle on one GPU.  Not thread-safe (same as the reference's one-model-per-process use)."""
+
+    def __init__(self, cfg: ModelConfig, max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32",
+                 device=None):
+        self.lib = capi.load()
+        self.device = _require_torch_cuda(device)
+        self.cfg = cfg
+        self.exit_config = cfg.exit_config
+        ec = self.exit_config
+        self.max_docs, self.max_text_len = int(max_docs), int(max_text_len)
+        self.E = ec.num_exits
+        self.K = cfg.num_labels
+        self.Kh = cfg.num_labels if str(ec.encoder_layer_strategy) == "ramp" else 2
+        c = capi.EEConfig()
+        c.abi_version = capi.ABI_VERSION
+        for f in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "vocab_size",
+                  "max_position_embeddings", "type_vocab_size", "pad_token_id", "max_2d_position_embeddings",
+                  "coordinate_size", "shape_size", "rel_pos_bins", "max_rel_pos", "rel_2d_pos_bins", "max_rel_2d_pos",
+                  "input_size", "patch_size", "num_channels", "num_labels"):
+            setattr(c, f, int(getattr(cfg, f)))
+        c.layer_norm_eps = float(cfg.layer_norm_eps)
+        emb = ec.embedding_exits
+        c.n_embedding_exits = len(emb)
+        for i, e in enumerate(emb):
+            c.embedding_exits[i] = capi.EXIT_KIND[e]
+        enc = ec.encoder_exit_layers
+        if len(enc) > capi.MAX_ENCODER_EXITS:
+            raise ValueError("too many encoder exits")
+        c.n_encoder_exits = len(enc)
+        for i, l in enumerate(enc):
+            c.encoder_exit_layers[i] = int(l)
+        c.exit_head_num_layers = int(ec.exit_head_num_layers)
+        c.strategy = 0 if str(ec.encoder_layer_strategy) == "ramp" else 1
+        c.criterion = ec.inference_strategy.code
+        c.max_docs, c.max_text_len = self.max_docs, self.max_text_len
+        c.precision = {"fp32": 0, "f32": 0, "bf16": 1}[precision]
+        self.precision = precision
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            capi.check(self.lib.ee_create(C.byref(c), C.byref(self._h)), None, "ee_create")
+        self._finalized = False
+
+    # ---- lifetime ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.ee_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ----------------------------------------------------------------------------------------------
+    def expected_tensors(self):
+        n = self.lib.ee_num_expected_tensors(self._h)
+        return [self.lib.ee_expected_tensor_name(self._h, i).decode() for i in range(n)]
+
+    def load_weights(self, weights: Mapping[str, Union[np.ndarray, "torch.Tensor"]], strict: bool = True):
+        """Copy parameters (HF names) into the handle.  Extra entries are ignored unless ``strict`` finds one missing."""
+        expected = self.expected_tensors()
+        missing = [n for n in expected if n not in weights]
+        if missing and strict:
+            raise KeyError(f"{len(missing)} parameter(s) missing from the checkpoint, e.g. {missing[:4]}")
+        with torch.cuda.device(self.device):
+            for name in expected:
+                if name not in weights:
+                    continue
+                t = weights[name]
+                if torch is not None and isinstance(t, torch.Tensor):
+                    t = t.detach()
+                    if t.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                        t = t.float()
+                    t = t.contiguous()
+                    dt = {torch.float32: capi.DT_F32, torch.float16: capi.DT_F16, torch.bfloat16: capi.DT_BF16}[t.dtype]
+                    if t.is_cuda and dt != capi.DT_F32:
+                        t = t.float()
+                        dt = capi.DT_F32
+                    shape = (C.c_int64 * t.dim())(*t.shape)
+                    rc = self.lib.ee_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), dt,
+                                                 1 if t.is_cuda else 0)
+                else:
+                    a = np.ascontiguousarray(np.asarray(t), dtype=np.float32)
+                    shape = (C.c_int64 * a.ndim)(*a.shape)
+                    rc = self.lib.ee_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim,
+                                                 capi.DT_F32, 0)
+                capi.check(rc, self._h, f"ee_load_tensor({name})")
+            capi.check(self.lib.ee_finalize(self._h), self._h, "ee_finalize")
+        self._finalized = True
+
+    @classmethod
+    def from_pretrained(cls, path: str, max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32",
+                        device=None, ee_config: Optional[dict] = None) -> "EarlyExitEngine":
+        """Load a local HF-format checkpoint directory (config.json with ``EE_config`` + safetensors / .bin), the
+        counterpart of ``LayoutLMv3EEForSequenceClassification.from_pretrained`` at EE/configs.py:404-411."""
+        cfg = ModelConfig.from_pretrained(path)
+        if ee_config:
+            cfg.EE_config.update(ee_config)
+        eng = cls(cfg, max_docs=max_docs, max_text_len=max_text_len, precision=precision, device=device)
+        eng.load_weights(load_checkpoint_tensors(path))
+        return eng
+
+    # ---- the hot path --------------------------------------------------------------------------------------------
+    def _dev(self, x, dtype, name, required=True):
+        if x is None:
+            if required:
+                raise ValueError(f"{name} is required")
+            return None
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        if not x.is_cuda or x.device != self.device:
+            x = x.to(self.device, non_blocking=True)
+        if x.dtype != dtype:
+            x = x.to(dtype)
+        return x.contiguous()
+
+    def forward(self, input_ids, attention_mask=None, bbox=None, pixel_values=None, token_type_ids=None,
+                position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
+                temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
+                want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
+                validate: bool = False) -> EngineOutput:
+        if not self._finalized:
+            raise capi.MMEEError("load_weights() has not been called")
+        ids = self._dev(input_ids, torch.int64, "input_ids")
+        B, T = ids.shape
+        if bbox is None:
+            bbox = torch.zeros((B, T, 4), dtype=torch.int64, device=self.device)   # EE/models/LayoutLMv3.py:433-436
+        am = self._dev(attention_mask, torch.int64, "attention_mask", required=False)
+        bb = self._dev(bbox, torch.int64, "bbox")
+        px = self._dev(pixel_values, torch.float32, "pixel_values")
+        tt = self._dev(token_type_ids, torch.int64, "token_type_ids", required=False)
+        ps = self._dev(position_ids, torch.int64, "position_ids", required=False)
+        R = self.cfg.input_size
+        if tuple(bb.shape) != (B, T, 4) or tuple(px.shape) != (B, self.cfg.num_channels, R, R):
+            raise ValueError(f"bbox must be (B,T,4) and pixel_values (B,{self.cfg.num_channels},{R},{R}); got "
+                             f"{tuple(bb.shape)} / {tuple(px.shape)}")
+        for t, n in ((am, "attention_mask"), (tt, "token_type_ids"), (ps, "position_ids")):
+            if t is not None and tuple(t.shape) != (B, T):
+                raise ValueError(f"{n} must be (B,T)")
+        E, K = self.E, self.K
+        if thresholds is None:
+            thresholds = self.exit_config.global_threshold
+        thr = np.broadcast_to(np.asarray(thresholds, dtype=np.float64).reshape(-1), (E + 1,)).copy() \
+            if np.ndim(thresholds) else np.full((E + 1,), float(thresholds))
+        thr_c = (C.c_double * (E + 1))(*thr.tolist())
+        tmp_c = None
+        if temperatures is not None:
+            tm = np.asarray(temperatures, dtype=np.float64).reshape(-1)
+            if tm.shape[0] != E + 1:
+                raise ValueError(f"temperatures must have {E + 1} entries")
+            tmp_c = (C.c_double * (E + 1))(*tm.tolist())
+        dev = self.device
+        out_logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+        out_exit = torch.empty((B,), dtype=torch.int32, device=dev)
+        out_conf = torch.empty((B,), dtype=torch.float32, device=dev)
+        nan = float("nan")
+        all_logits = torch.full((E + 1, B, K), nan, dtype=torch.float32, device=dev) if want_all else None
+        all_crit = torch.full((E + 1, B), nan, dtype=torch.float32, device=dev) if want_all else None
+        head_logits = torch.full((E, B, self.Kh), nan, dtype=torch.float32, device=dev) if want_head else None
+        head_crit = torch.full((E, B), nan, dtype=torch.float32, device=dev) if want_head else None
+        hidden = torch.full((self.cfg.num_hidden_layers + 1, B, self.cfg.hidden_size), nan, dtype=torch.float32,
+                            device=dev) if want_hidden_cls else None
+        flags = (capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = self.lib.ee_forward(self._h, p(ids), p(am), p(bb), p(px), p(tt), p(ps), B, T, thr_c, tmp_c, flags,
+                                     p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
+                                     p(head_logits), p(head_crit), p(hidden), stream)
+        capi.check(rc, self._h, "ee_forward")
+        self._keepalive = (ids, am, bb, px, tt, ps)   # borrowed by the enqueued kernels until the stream drains
+        if validate:
+            self.stage_counts()                        # synchronises; raises on out-of-range inputs
+        return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden)
+
+    __call__ = forward
+
+    # ---- statistics of the last forward (both synchronise) ----------------------------------------------------------
+    def stage_counts(self):
+        n = self.E + 1
+        docs, rows, ns = (C.c_int32 * n)(), (C.c_int32 * n)(), C.c_int32()
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(self.lib.ee_last_stage_counts(self._h, docs, rows, n, C.byref(ns), stream), self._h,
+                       "ee_last_stage_counts")
+        return {"docs": list(docs)[:ns.value], "rows": list(rows)[:ns.value]}
+
+    def profile(self, enable: bool = True):
+        """Arm / disarm per-kernel HIP-event timing of the following forward calls."""
+        capi.check(self.lib.ee_profile(self._h, 1 if enable else 0), self._h, "ee_profile")
+
+    def profile_read(self):
+        """{role: {"symbol", "ms", "launches"}} of the last forward run with profiling armed (synchronises)."""
+        out = {}
+        buf = C.create_string_buffer(160)
+        idx = 0
+        while True:
+            ms, n = C.c_double(), C.c_int32()
+            rc = self.lib.ee_profile_read(self._h, idx, buf, 160, C.byref(ms), C.byref(n))
+            if rc != 0:
+                break
+            role, _, sym = buf.value.decode().partition("|")
+            out[role] = {"symbol": sym, "ms": ms.value, "launches": n.value}
+            idx += 1
+        return out
+
+    def flops(self):
+        g, a = C.c_double(), C.c_double()
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(self.lib.ee_last_flops(self._h, C.byref(g), C.byref(a), stream), self._h, "ee_last_flops")
+        return {"gemm": g.value, "attention": a.value, "total": g.value + a.value}
+
+
+def load_checkpoint_tensors(path: str) -> Dict[str, "torch.Tensor"]:
+    """Read every tensor of a local HF checkpoint directory (safetensors preferred, then pytorch_model.bin)."""
+    st = [f for f in sorted(os.listdir(path)) if f.endswith(".safetensors")]
+    out: Dict[str, "torch.Tensor"] = {}
+    if st:
+        from safetensors import safe_open
+        for f in st:
+            with safe_open(os.path.join(path, f), framework="pt", device="cpu") as fh:
+                for k in fh.keys():
+                    out[k] = fh.get_tensor(k)
+        return out
+    bins = [f for f in sorted(os.listdir(path)) if f.endswith(".bin") or f.endswith(".pt")]
+    if not bins:
+        raise FileNotFoundError(f"no *.safetensors / *.bin under {path}")
+    for f in bins:
+        out.update(torch.load(os.path.join(path, f), map_location="cpu", weights_only=True))
+    return out
+
+
+def save_checkpoint(path: str, cfg: ModelConfig, weights: Mapping[str, np.ndarray]):
+    """Write an HF-format checkpoint directory (config.json with EE_config + model.safetensors)."""
+    from safetensors.numpy import save_file
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg.to_hf_dict(), f, indent=2)
+    save_file({k: np.ascontiguousarray(v) for k, v in weights.items()}, os.path.join(path, "model.safetensors"))

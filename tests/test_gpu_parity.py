@@ -1,0 +1,123 @@
+"""GPU parity: the HIP path (through the C-ABI) against the committed golden vectors and the oracle.
+
+Tolerances (north star): logits within 1e-4 abs of the reference CPU path, exit indices bit-exact.
+"""
+import numpy as np
+import pytest
+
+from .conftest import BASE_EE, TINY_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+
+
+def _engine(pkg, cfg, W, max_docs, T):
+    eng = pkg.EarlyExitEngine(cfg, max_docs=max_docs, max_text_len=T)
+    eng.load_weights(W)
+    return eng
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", list(TINY_CASES))
+@pytest.mark.parametrize("dense_rows", [False, True])
+def test_tiny_dump_all_matches_golden(pkg, name, dense_rows):
+    g = load_golden(name)
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES[name])
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    eng = _engine(pkg, cfg, W, max_docs=8, T=int(g["text_len"]))
+    out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True,
+                      dense_rows=dense_rows, want_all=True, want_head=True, want_hidden_cls=True, validate=True)
+    np.testing.assert_allclose(_np(out.hidden_cls), g["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(_np(out.head_logits), g["exit_logits"], rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(_np(out.head_crit), g["exit_crit"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(_np(out.all_logits), g["logits_store"], rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(_np(out.logits), g["logits"], rtol=0, atol=LOGIT_TOL)
+    E = g["exit_logits"].shape[0]
+    assert (_np(out.exit_layer) == E).all()
+    eng.close()
+
+
+def _margin_ok(store, thr, margin=1e-3):
+    e = np.exp(store - store.max(-1, keepdims=True))
+    conf = (e / e.sum(-1, keepdims=True)).max(-1)
+    return np.abs(conf - thr).min() > margin
+
+
+@pytest.mark.parametrize("dense_rows", [False, True])
+def test_tiny_early_exit_matches_reference_policy(pkg, oracle, dense_rows):
+    g = load_golden("tiny_ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    eng = _engine(pkg, cfg, W, max_docs=8, T=int(g["text_len"]))
+    for i in range(4):
+        thr = float(g[f"pol_thr{i}"])
+        assert _margin_ok(g["logits_store"], thr, 1e-5) or thr == 0.0 or thr > 1.0
+        out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], thresholds=thr,
+                          dense_rows=dense_rows, want_all=True)
+        ex = _np(out.exit_layer)
+        assert np.array_equal(ex, g[f"pol_exits{i}"]), (thr, ex, g[f"pol_exits{i}"])
+        np.testing.assert_allclose(_np(out.logits), g[f"pol_pred{i}"], rtol=0, atol=LOGIT_TOL)
+        counts = eng.stage_counts()
+        # documents entering stage e = documents that did not leave through an earlier exit
+        surv = [int((g[f"pol_exits{i}"] >= e).sum()) for e in range(len(counts["docs"]))]
+        assert counts["docs"] == surv
+        # exits that a document never reached stay NaN; reached ones match the store
+        al = _np(out.all_logits)
+        for n in range(al.shape[1]):
+            for e in range(al.shape[0]):
+                if e <= ex[n]:
+                    np.testing.assert_allclose(al[e, n], g["logits_store"][e, n], rtol=0, atol=LOGIT_TOL)
+                else:
+                    assert np.isnan(al[e, n]).all()
+    eng.close()
+
+
+def test_tiny_per_exit_thresholds_and_temperatures(pkg, oracle):
+    g = load_golden("tiny_ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    eng = _engine(pkg, cfg, W, max_docs=8, T=int(g["text_len"]))
+    E1 = g["logits_store"].shape[0]
+    rng = np.random.default_rng(3)
+    temps = rng.uniform(0.5, 3.0, E1)
+    store = oracle.temperature_scale(g["logits_store"], temps)
+    conf = oracle.softmax64(store).max(-1)
+    # per-exit threshold in the widest gap between neighbouring confidences (the exit test must not be ill-posed)
+    thr = np.zeros(E1)
+    for e in range(E1):
+        s = np.sort(conf[e])
+        k = int(np.argmax(np.diff(s)))
+        thr[e] = 0.5 * (s[k] + s[k + 1])
+    assert np.abs(conf - thr[:, None]).min() > 1e-4
+    ex, pred, cf = oracle.policy_scan(store, thr)
+    out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], thresholds=thr,
+                      temperatures=temps)
+    assert np.array_equal(_np(out.exit_layer), ex)
+    np.testing.assert_allclose(_np(out.logits), pred, rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(_np(out.confidence), cf, rtol=0, atol=1e-4)
+    eng.close()
+
+
+def test_base_shape_matches_golden(pkg):
+    g = load_golden("base_cls")
+    cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
+    eng = _engine(pkg, cfg, W, max_docs=4, T=512)
+    for dense in (False, True):
+        out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True,
+                          dense_rows=dense, want_all=True, want_hidden_cls=True, validate=True)
+        np.testing.assert_allclose(_np(out.hidden_cls), g["hidden_cls"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(_np(out.all_logits), g["logits_store"], rtol=0, atol=LOGIT_TOL)
+    for i in range(4):
+        out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"],
+                          thresholds=float(g[f"pol_thr{i}"]))
+        assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"])
+    eng.close()
