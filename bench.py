@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — docs/sec (+ mean exit layer) of the MI355X early-exit document-classification path.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+
+Workload (BASELINE.json configs[1]): LayoutLMv3-base, exit head every 2 layers (2,4,6,8,10) + final classifier, ramp
+policy (max-confidence thresholds, strict '>'), synthetic RVL-CDIP-shaped documents (512 text tokens padded + 197
+visual tokens), random-init weights.  One *step* = one pass of the hot path (ee_forward: embeddings ->
+encoder layers with on-device exit + compaction -> (logits, exit_layer, confidence)) over one batch that is already
+resident in HBM.  N > 1: documents shard data-parallel over the ranks (weak scaling, no data-path collective) and one
+RCCL all-gather of the per-document results closes the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the dominant kernel's launches
+(ee_profile); `cpu_baseline` times the CPU oracle (full depth, every exit, simulated policy — the reference's own
+semantics) on a bounded sample and doubles as a parity check of the same documents.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, Matrix cores: v_mfma_f32_32x32x2_f32 dense peak
+EXIT_LAYERS = [2, 4, 6, 8, 10]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="documents per step per GPU")
+    ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
+    ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
+    ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    return ap.parse_args()
+
+
+def calibrate_thresholds(conf, release):
+    """Per-exit thresholds (the interface of Policy.accuracy_calibration_heuristic, EE/policy.py:77-92) from one
+    dump-all pass: every exit releases the fraction ``release`` of the documents that reach it.  With random-init
+    weights the CLS states of different documents are strongly correlated, so ONE global threshold degenerates into
+    "an exit fires for everybody or nobody"; per-exit quantiles give the documented exit mix instead.  Each threshold
+    sits in the middle of a gap between neighbouring confidences so that the strict '>' test is well-posed."""
+    E1, n = conf.shape
+    active = np.ones(n, dtype=bool)
+    thr = np.full(E1, 2.0)
+    for e in range(E1 - 1):
+        c = np.sort(conf[e, active])
+        if len(c) < 2:
+            break
+        k = int(round((1.0 - release) * len(c)))
+        k = min(max(k, 1), len(c) - 1)
+        # widest gap in a small window around the quantile
+        lo, hi = max(1, k - 3), min(len(c) - 1, k + 3)
+        j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
+        thr[e] = 0.5 * (c[j - 1] + c[j])
+        active &= ~(conf[e] > thr[e])
+    return thr
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    pkg = importlib.import_module("multi-modal-early-exit_amd")
+
+    ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+    cfg = pkg.ModelConfig.base(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=a.seed, head_gain=6.0)
+    B, T = a.batch, 512
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev)
+    eng.load_weights(W)
+    docs = pkg.synth.make_documents(cfg, B, seed=a.seed + 1000 * rank, text_len=T)
+    d_ids = torch.from_numpy(docs["input_ids"]).to(dev)
+    d_am = torch.from_numpy(docs["attention_mask"]).to(dev)
+    d_bb = torch.from_numpy(docs["bbox"]).to(dev)
+    d_px = torch.from_numpy(docs["pixel_values"]).to(dev)
+
+    # ---- threshold calibration on the resident batch (untimed): dump-all pass -> confidences -> global threshold ----
+    out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows)
+    conf = out.all_crit.cpu().numpy().astype(np.float64)
+    thr = calibrate_thresholds(conf, a.release)
+    if world > 1:                       # every rank uses rank 0's thresholds
+        t = torch.from_numpy(thr).to(dev)
+        dist.broadcast(t, 0)
+        thr = t.cpu().numpy()
+
+    def step():
+        return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows)
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(a.steps):
+        out = step()
+        results.append(torch.cat([out.logits, out.exit_layer.float().unsqueeze(1), out.confidence.unsqueeze(1)], dim=1))
+    local_res = torch.cat(results, dim=0)
+    if world > 1:                       # the one collective of the path: per-document (logits, exit, confidence)
+        gathered = torch.empty((world * local_res.shape[0], local_res.shape[1]), dtype=local_res.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, local_res)
+    else:
+        gathered = local_res
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    n_docs = gathered.shape[0]
+    exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
+    layer_of_exit = np.array(EXIT_LAYERS + [cfg.num_hidden_layers])
+    counts = eng.stage_counts()
+    fl = eng.flops()
+
+    line = {
+        "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: LayoutLMv3-base, exits at layers 2/4/6/8/10 + final, ramp, "
+                               "per-exit max-confidence thresholds, S=512+197, synthetic RVL-CDIP-shaped docs, random-init weights",
+                   "docs_per_step_per_gpu": B, "text_len": T, "rows_layout": "dense" if a.dense_rows else "ragged",
+                   "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
+                   "release_fraction_per_exit": a.release},
+        "mean_exit_layer": float(layer_of_exit[exits].mean()), "mean_exit_index": float(exits.mean()),
+        "exit_distribution": {str(int(layer_of_exit[e])): float((exits == e).mean()) for e in range(len(layer_of_exit))},
+        "stage_docs_last_step_rank0": counts["docs"], "executed_tflop_per_step_rank0": fl["total"] / 1e12,
+        "executed_tflops_rank0": fl["total"] / (dt / a.steps) / 1e12,
+    }
+
+    if rank == 0 and not a.no_profile:
+        # ---- roofline of the dominant kernel, live: HIP events around every launch of one more (untimed) step ------
+        eng.profile(True)
+        step()
+        prof = eng.profile_read()
+        eng.profile(False)
+        c = eng.stage_counts()
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        stage_of_layer, s = [], 0
+        for l in range(cfg.num_hidden_layers):
+            stage_of_layer.append(s)
+            if (l + 1) in EXIT_LAYERS:
+                s += 1
+        rows = [c["rows"][st] for st in stage_of_layer]
+        up_flops = sum(2.0 * r * H * I for r in rows)                  # algorithmic FLOPs of the FFN-up launches
+        up = prof["gemm_ffn_up"]
+        gemm_ms = sum(prof[k]["ms"] for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn_up", "gemm_ffn_down", "gemm_patch"))
+        ach = up_flops / (up["ms"] * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel<1,0> (FFN up + GELU)", "achieved": ach,
+                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                            "traffic": None, "launches": up["launches"], "avg_launch_ms": up["ms"] / max(1, up["launches"]),
+                            "flops_per_launch_avg": up_flops / max(1, up["launches"])}
+        tot = sum(v["ms"] for v in prof.values())
+        line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
+        fl2 = eng.flops()
+        line["gemm_class_tflops"] = fl2["gemm"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+        line["attention_tflops"] = fl2["attention"] / (prof["attention"]["ms"] * 1e-3) / 1e12 if prof["attention"]["ms"] else None
+
+    if rank == 0 and a.cpu_docs != 0:
+        # ---- CPU baseline: the oracle = the reference's semantics (every layer, every exit, simulated policy), B=1 ---
+        oracle = importlib.import_module("oracle.ee_oracle")
+        cores = min(16, os.cpu_count() or 1)        # the box's CPU share for one GPU; BLAS oversubscribes beyond it
+        try:
+            from threadpoolctl import threadpool_limits
+            threadpool_limits(limits=cores)
+        except Exception:
+            cores = os.cpu_count() or 1
+        one = {k: v[:1] for k, v in docs.items()}
+        t1 = time.perf_counter()
+        r0 = oracle.forward_all(cfg, W, one, ee["exits"])
+        per_doc = time.perf_counter() - t1
+        n = a.cpu_docs if a.cpu_docs > 0 else int(min(16, max(2, round(15.0 / max(per_doc, 1e-3)))))
+        t1 = time.perf_counter()
+        stores = [r0["logits_store"]]
+        for i in range(1, n):
+            stores.append(oracle.forward_all(cfg, W, {k: v[i:i + 1] for k, v in docs.items()}, ee["exits"])["logits_store"])
+        store = np.concatenate(stores, axis=1)
+        ex_cpu, pred_cpu, _ = oracle.policy_scan(store, thr)
+        cpu_dt = per_doc + (time.perf_counter() - t1)
+        line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "docs/s", "cores": cores, "kind": "port",
+                                "sample": f"{n} documents of the same batch, B=1 per forward (reference default "
+                                          f"eval_batch_size=1), full depth + all exits + simulated policy, numpy/OpenBLAS "
+                                          f"float32 on {cores} host threads"}
+        g_ex = out.exit_layer.cpu().numpy()[:n] if world == 1 else exits[:n]
+        g_lg = gathered[:n, :cfg.num_labels].cpu().numpy() if world > 1 else out.logits.cpu().numpy()[:n]
+        line["parity_vs_cpu_sample"] = {"docs": n, "exit_index_equal": bool(np.array_equal(g_ex, ex_cpu)),
+                                        "max_abs_dlogit": float(np.abs(g_lg - pred_cpu).max())}
+    if rank == 0:
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

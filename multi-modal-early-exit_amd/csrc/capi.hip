@@ -724,7 +724,8 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
 
 int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const double* thresholds, int32_t* exits,
                    double* predictions, double* confidence, int32_t* counts, void* stream) {
-    if (!logits || !thresholds || !exits || E1 < 1 || E1 > 256 || N < 0 || K < 1) return fail(nullptr, "ee_policy_scan: bad argument");
+    if (!thresholds || E1 < 1 || E1 > 256 || N < 0 || K < 1 || (N > 0 && (!logits || !exits)))
+        return fail(nullptr, "ee_policy_scan: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_policy_scan: no HIP device");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -1,0 +1,65 @@
+"""Data-parallel sharding of the path over the GPUs of one node.
+
+Every document is independent in the forward pass and in the policy (EE/policy.py:28-45 loops per sample; thresholds
+and temperatures are precomputed inputs), so the path shards with NO data-path collective: one process per GPU, each
+owning a round-robin slice of the documents (interleaved so that expected exit depth is balanced across ranks), the
+weights replicated.  The single collective is one all-gather of the per-document results
+``[logits (K) | exit_layer | confidence]`` at the end (RCCL over xGMI on GPUs: backend "nccl"; "gloo" in CPU tests).
+The reference has no counterpart (its ``--data-parallel`` flag, EE/configs.py:116-121, is never read).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from .engine import torch
+
+
+def shard_indices(n_docs: int, rank: int, world: int) -> np.ndarray:
+    """Documents of ``rank``: rank, rank + world, rank + 2*world, ..."""
+    return np.arange(rank, n_docs, world, dtype=np.int64)
+
+
+def shard_size(n_docs: int, rank: int, world: int) -> int:
+    return (n_docs - rank + world - 1) // world if n_docs > rank else 0
+
+
+def pack_results(logits, exit_layer, confidence):
+    """(n, K) float, (n,) int, (n,) float -> (n, K+2) float32 rows (exit index is exact in float32 below 2**24)."""
+    return torch.cat([logits.float(), exit_layer.float().unsqueeze(1), confidence.float().unsqueeze(1)], dim=1)
+
+
+def unpack_results(rows):
+    K = rows.shape[1] - 2
+    return rows[:, :K], rows[:, K].round().to(torch.int32), rows[:, K + 1]
+
+
+def all_gather_results(local_rows, n_docs: int, rank: int, world: int, group=None):
+    """One all-gather of every rank's ``(n_local, C)`` rows; returns ``(n_docs, C)`` in original document order.
+    Shards may differ by one row: each rank pads to the largest shard so a single fixed-size collective suffices."""
+    import torch.distributed as dist
+    if world == 1:
+        return local_rows
+    n_max = shard_size(n_docs, 0, world)
+    C = local_rows.shape[1]
+    if local_rows.shape[0] != shard_size(n_docs, rank, world):
+        raise ValueError(f"rank {rank} holds {local_rows.shape[0]} rows, expected {shard_size(n_docs, rank, world)}")
+    buf = torch.zeros((n_max, C), dtype=local_rows.dtype, device=local_rows.device)
+    buf[:local_rows.shape[0]] = local_rows
+    out = torch.empty((world * n_max, C), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    # rank r, local row i  <->  document r + i * world
+    res = torch.empty((n_docs, C), dtype=local_rows.dtype, device=local_rows.device)
+    for r in range(world):
+        n_r = shard_size(n_docs, r, world)
+        if n_r:
+            res[r::world][:n_r] = out[r * n_max:r * n_max + n_r]
+    return res
+
+
+def run_sharded(run_local: Callable, n_docs: int, rank: int, world: int, group=None):
+    """``run_local(doc_indices) -> (n_local, K+2) rows`` on this rank's shard, then the one all-gather."""
+    idx = shard_indices(n_docs, rank, world)
+    rows = run_local(idx)
+    return all_gather_results(rows, n_docs, rank, world, group)

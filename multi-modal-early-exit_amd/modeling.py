@@ -1,0 +1,201 @@
+"""The reference's model surface on top of the HIP path.
+
+``LayoutLMv3EEForSequenceClassification.forward`` keeps the signature and the return contract of
+EE/models/LayoutLMv3.py:696-711, 887-896 (``EESequenceClassifierOutput`` fields of EE/models/EE_modules.py:231-273), so
+``utils.get_logits`` (EE/utils.py:179-193), ``eval.py`` and ``analysis.py`` consume it unchanged:
+
+* like the reference (whose in-forward exit is commented out, EE/models/LayoutLMv3.py:270-281) ``forward`` evaluates
+  EVERY exit for every document — it runs the HIP path in dump-all mode;
+* ``early_exit`` is the new fast path of the north star: the policy test runs on the device between layers and
+  documents that satisfy it leave; it returns ``(logits, exit_layer, confidence)``.
+
+No arithmetic of the path happens here: tensors in, pointers across the C-ABI, tensors out.  The cross-entropy values
+reported when ``labels`` are passed (``loss`` / ``exit_losses``, EE/models/LayoutLMv3.py:756-869) are evaluation
+by-products computed from the returned logits.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from types import SimpleNamespace
+from typing import Any, Dict, Iterator, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import capi
+from .config import ExitConfig, ModelConfig
+from .engine import EarlyExitEngine, EngineOutput, load_checkpoint_tensors, torch
+
+
+class _ModelOutput(OrderedDict):
+    """Minimal stand-in for ``transformers.ModelOutput``: attribute, key and integer access; ``None`` fields are
+    skipped by integer indexing / ``to_tuple`` exactly as HF does."""
+
+    _fields: Tuple[str, ...] = ()
+
+    def __init__(self, **kw):
+        super().__init__()
+        for f in self._fields:
+            v = kw.get(f)
+            object.__setattr__(self, f, v)
+            if v is not None:
+                self[f] = v
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return super().__getitem__(k)
+        return self.to_tuple()[k]
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys())
+
+
+class EEModelOutput(_ModelOutput):  # EE/models/EE_modules.py:198-228
+    _fields = ("last_hidden_state", "hidden_states", "attentions", "exit_states", "gate_inputs", "lte_output")
+
+
+class EESequenceClassifierOutput(_ModelOutput):  # EE/models/EE_modules.py:231-273
+    _fields = ("logits", "loss", "hidden_states", "attentions", "exit_losses", "exit_criteria", "exit_states",
+               "gated_logits", "lte_output")
+
+
+class LayoutLMv3EEForSequenceClassification:
+    """Drop-in for the reference class of the same name (inference only)."""
+
+    def __init__(self, config: Union[ModelConfig, Mapping[str, Any]], weights: Optional[Mapping[str, Any]] = None,
+                 max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32", device=None):
+        if not isinstance(config, ModelConfig):
+            config = ModelConfig.from_hf_dict(dict(config))
+        self.model_config = config
+        self.engine = EarlyExitEngine(config, max_docs=max_docs, max_text_len=max_text_len, precision=precision,
+                                      device=device)
+        ec = config.exit_config
+        # what callers read: .config.exit_config[...] / .num_labels / .id2label (EE/utils.py:62-78, 142-144, 161)
+        self.config = SimpleNamespace(
+            exit_config={"training_strategy": ec.training_strategy, "inference_strategy": ec.inference_strategy,
+                         "global_threshold": ec.global_threshold, "exits": list(ec.exits),
+                         "encoder_layer_strategy": ec.encoder_layer_strategy,
+                         "exit_head_num_layers": ec.exit_head_num_layers},
+            EE_config=dict(config.EE_config), num_labels=config.num_labels,
+            id2label={i: f"LABEL_{i}" for i in range(config.num_labels)}, use_return_dict=True,
+            hidden_size=config.hidden_size, num_hidden_layers=config.num_hidden_layers)
+        self.num_labels = config.num_labels
+        self.apply_gating = str(ec.encoder_layer_strategy) == "gate"
+        self.processor = None          # offline: no AutoProcessor (EE/models/LayoutLMv3.py:674-677 fetches one)
+        self.training = False
+        self._weights = None
+        if weights is not None:
+            self.load_weights(weights)
+
+    # ---- loading ----------------------------------------------------------------------------------------------------
+    def load_weights(self, weights: Mapping[str, Any]):
+        self.engine.load_weights(weights)
+        self._weights = weights
+
+    @classmethod
+    def from_pretrained(cls, path: str, config: Optional[Any] = None, **kw) -> "LayoutLMv3EEForSequenceClassification":
+        """Local HF-format checkpoint directory only (EE/configs.py:389-411); hub names cannot be fetched offline."""
+        cfg = ModelConfig.from_pretrained(path)
+        ee = getattr(config, "EE_config", None) if config is not None else None
+        if ee:
+            cfg.EE_config.update({k: (str(v) if hasattr(v, "value") else v) for k, v in dict(ee).items()})
+        m = cls(cfg, **kw)
+        m.load_weights(load_checkpoint_tensors(path))
+        return m
+
+    # ---- nn.Module-ish surface the harness touches -------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.engine.device
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def named_parameters(self) -> Iterator[Tuple[str, Any]]:
+        if self._weights is None:
+            return iter(())
+        return ((k, v) for k, v in self._weights.items())
+
+    def exit_criterion(self, logits):
+        """``max_confidence`` / ``entropy`` on a logits tensor (EE/models/EE_modules.py:149-160)."""
+        if str(self.model_config.exit_config.inference_strategy) == "max_confidence":
+            return torch.softmax(logits, dim=1).max(dim=1)[0]
+        e = torch.exp(logits)
+        return torch.log(e.sum(1)) - (logits * e).sum(1) / e.sum(1)
+
+    # ---- chunked engine call -------------------------------------------------------------------------------------------
+    def _run(self, tensors: Dict[str, Any], **kw) -> EngineOutput:
+        ids = tensors["input_ids"]
+        B = ids.shape[0]
+        mb = self.engine.max_docs
+        if B <= mb:
+            return self.engine.forward(**tensors, **kw)
+        parts = []
+        for s in range(0, B, mb):
+            sl = {k: (v[s:s + mb] if v is not None else None) for k, v in tensors.items()}
+            parts.append(self.engine.forward(**sl, **kw))
+        cat = lambda xs, d: None if xs[0] is None else torch.cat(xs, dim=d)
+        return EngineOutput(cat([p.logits for p in parts], 0), cat([p.exit_layer for p in parts], 0),
+                            cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
+                            cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
+                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1))
+
+    # ---- the reference signature -------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, bbox=None, pixel_values=None, labels=None,
+                token_type_ids=None, position_ids=None, head_mask=None, inputs_embeds=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, **kwargs) -> EESequenceClassifierOutput:
+        if input_ids is None or pixel_values is None:
+            raise ValueError("the HIP path implements the multimodal evaluation input: input_ids AND pixel_values "
+                             "(EE/utils.py:93-98); inputs_embeds / text-only / image-only calls are not built")
+        if inputs_embeds is not None or head_mask is not None:
+            raise NotImplementedError("inputs_embeds / head_mask are not part of the evaluation hot path")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / full hidden states are never materialised by the fused kernels; "
+                                      "EarlyExitEngine.forward(want_hidden_cls=True) returns the CLS row of every layer")
+        out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
+                             token_type_ids=token_type_ids, position_ids=position_ids),
+                        dump_all=True, want_all=True, want_head=True)
+        E = self.engine.E
+        logits = out.all_logits[E]
+        exit_states = tuple((out.head_logits[j], out.head_crit[j]) for j in range(E))
+        gated, exit_criteria, exit_losses, loss = (), [], [], None
+        if labels is not None:
+            lab = labels.to(logits.device).view(-1) if torch.is_tensor(labels) else torch.as_tensor(labels, device=logits.device).view(-1)
+            F = torch.nn.functional
+            loss = F.cross_entropy(logits, lab)
+            if self.apply_gating:                              # EE/models/LayoutLMv3.py:764-792
+                gated = tuple(out.all_logits[j] for j in range(E))
+                for j in range(E):
+                    y = torch.zeros(lab.shape[0], 2, device=logits.device)
+                    y[torch.arange(lab.shape[0]), (gated[j].argmax(-1) == lab).long()] = 1
+                    exit_losses.append(F.binary_cross_entropy_with_logits(out.head_logits[j], y))
+                    exit_criteria.append(out.head_crit[j])
+            else:                                              # :860-869
+                for j in range(E):
+                    exit_losses.append(F.cross_entropy(out.head_logits[j], lab))
+                    exit_criteria.append(out.head_crit[j])
+        exit_criteria.append(out.all_crit[E])                  # :871-872
+        res = EESequenceClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None,
+                                         exit_losses=exit_losses, exit_criteria=exit_criteria, exit_states=exit_states,
+                                         gated_logits=gated)
+        if return_dict is False:
+            return res.to_tuple()
+        return res
+
+    __call__ = forward
+
+    # ---- the fast path ------------------------------------------------------------------------------------------------
+    def early_exit(self, input_ids, attention_mask=None, bbox=None, pixel_values=None, token_type_ids=None,
+                   position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
+                   temperatures: Optional[Sequence[float]] = None, **kw) -> EngineOutput:
+        """(logits, exit_layer, confidence) with the policy test on the device: identical to running ``forward`` on
+        everything and then ``Policy(...)`` (EE/eval.py:87-98), but deeper layers only see the surviving documents.
+        ``thresholds`` defaults to ``config.exit_config["global_threshold"]``."""
+        if thresholds is None:
+            thresholds = self.config.exit_config["global_threshold"]
+        return self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
+                              token_type_ids=token_type_ids, position_ids=position_ids),
+                         thresholds=thresholds, temperatures=temperatures, **kw)

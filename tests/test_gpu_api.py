@@ -1,0 +1,128 @@
+"""GPU: the reference-shaped surfaces (model.forward, Policy, harness) and the auxiliary kernels through the C-ABI."""
+import numpy as np
+import pytest
+
+from .conftest import TINY_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(pkg, name, g, **kw):
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES[name])
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    return pkg.LayoutLMv3EEForSequenceClassification(cfg, W, max_docs=kw.pop("max_docs", 8), max_text_len=int(g["text_len"]))
+
+
+def _batch(g):
+    import torch
+    return {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("in_")}
+
+
+@pytest.mark.parametrize("name", list(TINY_CASES))
+def test_model_forward_contract(pkg, name):
+    g = load_golden(name)
+    m = _model(pkg, name, g, max_docs=4)          # 6 documents through a 4-document engine: exercises chunking
+    out = m.forward(**_batch(g))
+    E = g["exit_logits"].shape[0]
+    np.testing.assert_allclose(out.logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+    assert len(out.exit_states) == E and out.loss is not None and len(out.exit_losses) == E
+    for j in range(E):
+        np.testing.assert_allclose(out.exit_states[j][0].cpu().numpy(), g["exit_logits"][j], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out.exit_states[j][1].cpu().numpy(), g["exit_crit"][j], rtol=0, atol=2e-5)
+    assert len(out.exit_criteria) == E + 1                         # labels were passed (EE/models/LayoutLMv3.py:756-872)
+    np.testing.assert_allclose(out.exit_criteria[-1].cpu().numpy(), g["final_crit"], rtol=0, atol=2e-5)
+    if "gated_logits" in g:
+        assert len(out.gated_logits) == E
+        for j in range(E):
+            np.testing.assert_allclose(out.gated_logits[j].cpu().numpy(), g["gated_logits"][j], rtol=0, atol=1e-4)
+    else:
+        assert len(out.gated_logits) == 0
+    b = _batch(g)
+    b.pop("labels")
+    out2 = m.forward(**b)
+    assert out2.loss is None and len(out2.exit_criteria) == 1 and len(out2.gated_logits) == 0
+    with pytest.raises(NotImplementedError):
+        m.forward(**b, output_hidden_states=True)
+
+
+def test_harness_store_matches_golden_and_policy_roundtrip(pkg, tmp_path):
+    import torch
+    for name in ("tiny_ramp", "tiny_gate"):
+        g = load_golden(name)
+        m = _model(pkg, name, g)
+        b = _batch(g)
+        loader = [{k: v[i:i + 2] for k, v in b.items()} for i in range(0, 6, 2)]
+        cfg = {"checkpoint": name, "test_dataset": "synthetic", "downsampling": 0, "labelset": "test"}
+        store, refs, _ = pkg.harness.get_logits(m, cfg, loader, root=str(tmp_path))
+        np.testing.assert_allclose(store, g["logits_store"], rtol=0, atol=1e-4)
+        assert np.array_equal(refs, g["in_labels"])
+    g = load_golden("tiny_ramp")
+    for i in range(4):
+        pol = pkg.Policy(g["logits_store"], {"exit_threshold": float(g[f"pol_thr{i}"]), "device": "cpu"})
+        ex, pred, dist = pol.max_confidence_global_thresholding_policy()
+        assert ex.dtype == np.int32 and np.array_equal(ex, g[f"pol_exits{i}"])
+        assert pred.dtype == torch.float64 and pred.device.type == "cpu"
+        np.testing.assert_array_equal(pred.numpy(), g[f"pol_pred{i}"])
+        np.testing.assert_allclose([dist[k] for k in sorted(dist)], g[f"pol_dist{i}"])
+
+
+def test_policy_kernel_matches_reference_policy_vectors(pkg, oracle):
+    g = load_golden("policy_random")
+    for i in range(5):
+        pol = pkg.Policy(g["logits_store"], {"exit_threshold": float(g[f"pol_thr{i}"]), "device": "cpu"})
+        ex, pred, dist = pol.max_confidence_global_thresholding_policy()
+        assert np.array_equal(ex, g[f"pol_exits{i}"])
+        np.testing.assert_array_equal(pred.numpy(), g[f"pol_pred{i}"])
+        np.testing.assert_allclose([dist[k] for k in sorted(dist)], g[f"pol_dist{i}"])
+    cfg = {"exit_threshold": 0.5, "device": "cpu", "epsilon": float(g["heur_eps"]),
+           "calibration_metrics": {"accuracy": list(g["heur_accuracy"]), "ece": list(g["heur_ece"]),
+                                   "average_confidence": list(g["heur_avgconf"])}}
+    ex, pred, dist = pkg.Policy(g["logits_store"], cfg).accuracy_calibration_heuristic()
+    assert np.array_equal(ex, g["heur_exits"])
+    np.testing.assert_array_equal(pred.numpy(), g["heur_pred"])
+    np.testing.assert_allclose([dist[k] for k in sorted(dist)], g["heur_dist"])
+    with pytest.raises(Exception):
+        pkg.Policy(g["logits_store"], {"exit_threshold": 0.5, "device": "cpu"}).accuracy_calibration_heuristic()
+
+
+def test_policy_kernel_full_size_properties(pkg, oracle):
+    """BASELINE config 2 size (7 x 40000 x 16): equality with the vectorised oracle + size-independent properties."""
+    rng = np.random.default_rng(0)
+    store = rng.standard_normal((7, 40000, 16)) * 2.5
+    conf = oracle.softmax64(store).max(-1)
+    for thr in (0.0, 0.4, 0.7, 1.0 + 1e-6):
+        ex_o, pred_o, cf_o = oracle.policy_scan(store, thr)
+        ex, pred, cf, counts = pkg.policy_scan_device(store, thr, want_conf=True)
+        ex, pred, cf, counts = ex.cpu().numpy(), pred.cpu().numpy(), cf.cpu().numpy(), counts.cpu().numpy()
+        near = np.abs(conf - thr).min(0) < 1e-12                      # exp() may differ in the last ulp
+        assert np.array_equal(ex[~near], ex_o[~near]) and near.sum() < 4
+        assert np.array_equal(pred[~near], pred_o[~near])
+        np.testing.assert_allclose(cf[~near], cf_o[~near], rtol=1e-12)
+        assert counts.sum() == 40000 and np.array_equal(counts, np.bincount(ex, minlength=7))
+    # monotone: raising the threshold never makes a document leave earlier
+    e1 = pkg.policy_scan_device(store, 0.4)[0].cpu().numpy()
+    e2 = pkg.policy_scan_device(store, 0.7)[0].cpu().numpy()
+    assert (e2 >= e1).all()
+    # empty input
+    ex, pred, _, counts = pkg.policy_scan_device(np.zeros((3, 0, 5)), 0.5)
+    assert ex.numel() == 0 and counts.sum().item() == 0
+
+
+def test_input_validation_flags(pkg):
+    g = load_golden("tiny_ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48)
+    with pytest.raises(pkg.capi.MMEEError):
+        eng.forward(g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"])   # weights not loaded
+    eng.load_weights(pkg.synth.make_weights(cfg, seed=7))
+    bad = g["in_bbox"].copy()
+    bad[0, 1, 2] = 5000
+    with pytest.raises(pkg.capi.MMEEError, match="out of range"):
+        eng.forward(g["in_input_ids"], g["in_attention_mask"], bad, g["in_pixel_values"], validate=True)
+    with pytest.raises(pkg.capi.MMEEError):
+        eng.forward(np.zeros((9, 48), np.int64), None, np.zeros((9, 48, 4), np.int64), np.zeros((9, 3, 64, 64), np.float32))
+    W = pkg.synth.make_weights(cfg, seed=7)
+    W.pop("classifier.dense.weight")
+    with pytest.raises(KeyError):
+        pkg.EarlyExitEngine(cfg, max_docs=2, max_text_len=48).load_weights(W)
+    eng.close()
