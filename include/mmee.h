@@ -138,13 +138,19 @@ int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const
                    int32_t* exits, double* predictions, double* confidence, int32_t* counts, void* stream);
 
 /*
- * Many threshold vectors at once over precomputed confidences (EE/thresh.py:184-215 / EE/large_scale.py:68-84
- * semantics: exit = argmax_e(conf[e,n] >= thr[v,e]), i.e. first exit whose confidence reaches its threshold, 0 when
- * none does).  conf dev float (E1,N), correct dev uint8 (E1,N) (1 = exit e classifies doc n correctly),
- * thr dev float (V,E1).  Outputs dev: acc double (V,), mean_exit double (V,), exit_hist int32 (V,E1) or NULL.
+ * Many threshold vectors at once over a confidence table (EE/thresh.py:184-215 / EE/large_scale.py:42-84 semantics:
+ * exit(v,n) = argmax_e(conf[e,n] >= thr[v,e]) = first exit whose confidence reaches its threshold, 0 when none does;
+ * accuracy = mean(correct[exit(v,n), n]), average exit = mean(exit(v,n)), EE/large_scale.py:87-96).
+ * conf dev double (E1,N) (float64 like the reference's CSF table), correct dev uint8 (E1,N), thr dev double (V,E1).
+ * Outputs dev: acc double (V,), mean_exit double (V,), exit_hist int32 (V,E1) or NULL.
  */
-int ee_threshold_sweep(const float* conf, const uint8_t* correct, int32_t E1, int32_t N, const float* thr, int32_t V,
+int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, int32_t N, const double* thr, int32_t V,
                        double* acc, double* mean_exit, int32_t* exit_hist, void* stream);
+/* The confidence table of the sweep: conf[e,n] = max softmax (float64) of logits[e,n,:] (CSF "msp", EE/thresh.py:55-57),
+ * correct[e,n] = (argmax_k logits[e,n,k] == references[n]).  logits dev double (E1,N,K); references dev int64 (N,) or NULL
+ * with correct NULL. */
+int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, int32_t N, int32_t K, double* conf,
+                 uint8_t* correct, void* stream);
 
 /* Per-kernel timing of subsequent ee_forward calls with HIP events recorded on the launch stream (adds two event
  * records per launch; keep it off in timed runs).  ee_profile(h, 1) arms it and clears old records; every ee_forward

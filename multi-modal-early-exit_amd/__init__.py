@@ -13,3 +13,4 @@ from .modeling import (EEModelOutput, EESequenceClassifierOutput,  # noqa: F401,
 from .policy import Policy, policy_scan_device  # noqa: F401,E402
 from . import harness  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
+from . import sweep  # noqa: F401,E402

@@ -740,7 +740,7 @@ int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const
     return 0;
 }
 
-int ee_threshold_sweep(const float* conf, const uint8_t* correct, int32_t E1, int32_t N, const float* thr, int32_t V, double* acc,
+int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, int32_t N, const double* thr, int32_t V, double* acc,
                        double* mean_exit, int32_t* exit_hist, void* stream) {
     if (!conf || !correct || !thr || !acc || !mean_exit || E1 < 1 || E1 > 64 || N < 1 || V < 0)
         return fail(nullptr, "ee_threshold_sweep: bad argument");
@@ -748,6 +748,16 @@ int ee_threshold_sweep(const float* conf, const uint8_t* correct, int32_t E1, in
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_threshold_sweep: no HIP device");
     if (V > 0) launch_threshold_sweep(conf, correct, E1, N, thr, V, acc, mean_exit, exit_hist, reinterpret_cast<hipStream_t>(stream));
     if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_threshold_sweep: launch failed");
+    return 0;
+}
+
+int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, int32_t N, int32_t K, double* conf, uint8_t* correct,
+                 void* stream) {
+    if (!logits || !conf || E1 < 1 || N < 1 || K < 1) return fail(nullptr, "ee_msp_table: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_msp_table: no HIP device");
+    launch_msp_table(logits, (const long long*)references, E1, N, K, conf, correct, reinterpret_cast<hipStream_t>(stream));
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_msp_table: launch failed");
     return 0;
 }
 

@@ -272,11 +272,11 @@ void launch_policy_scan(const double* logits, int E1, int N, int K, const double
 //   exit(v, n) = first e with conf[e][n] >= thr[v][e], else 0 (numpy argmax of an all-False column)
 // conf is (E1, N) so consecutive threads read consecutive documents of the same exit row (coalesced).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void threshold_sweep_kernel(const float* __restrict__ conf, const unsigned char* __restrict__ correct,
-                                                              int E1, int N, const float* __restrict__ thr, int V,
+__global__ __launch_bounds__(256) void threshold_sweep_kernel(const double* __restrict__ conf, const unsigned char* __restrict__ correct,
+                                                              int E1, int N, const double* __restrict__ thr, int V,
                                                               double* __restrict__ acc, double* __restrict__ mean_exit,
                                                               int* __restrict__ hist) {
-    __shared__ float s_thr[64];
+    __shared__ double s_thr[64];
     __shared__ int s_hist[64];
     __shared__ unsigned long long s_red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,11 +307,37 @@ __global__ __launch_bounds__(256) void threshold_sweep_kernel(const float* __res
     }
 }
 
-void launch_threshold_sweep(const float* conf, const unsigned char* correct, int E1, int N, const float* thr, int V,
+void launch_threshold_sweep(const double* conf, const unsigned char* correct, int E1, int N, const double* thr, int V,
                             double* acc, double* mean_exit, int* hist, hipStream_t s) {
     int grid = V < 8192 ? V : 8192;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(threshold_sweep_kernel, dim3(grid), dim3(256), 0, s, conf, correct, E1, N, thr, V, acc, mean_exit, hist);
+}
+
+// conf[e][n] = max softmax (f64) of logits[e][n][:], correct[e][n] = (argmax == reference[n])   (first maximum wins, as numpy)
+__global__ __launch_bounds__(256) void msp_table_kernel(const double* __restrict__ logits, const long long* __restrict__ refs,
+                                                        int E1, int N, int K, double* __restrict__ conf,
+                                                        unsigned char* __restrict__ correct) {
+    const size_t total = (size_t)E1 * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const double* z = logits + i * K;
+        double m = z[0];
+        int am = 0;
+        for (int k = 1; k < K; ++k)
+            if (z[k] > m) { m = z[k]; am = k; }
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s += exp(z[k] - m);
+        conf[i] = 1.0 / s;
+        if (correct) correct[i] = refs ? (unsigned char)(refs[i % N] == am) : 0;
+    }
+}
+
+void launch_msp_table(const double* logits, const long long* refs, int E1, int N, int K, double* conf, unsigned char* correct,
+                      hipStream_t s) {
+    size_t total = (size_t)E1 * N;
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(msp_table_kernel, dim3(grid), dim3(256), 0, s, logits, refs, E1, N, K, conf, correct);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

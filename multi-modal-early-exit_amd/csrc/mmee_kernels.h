@@ -98,8 +98,10 @@ void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_
                        float* out, int max_docs, hipStream_t s);
 void launch_policy_scan(const double* logits, int E1, int N, int K, const double* thr_dev, int* exits, double* pred,
                         double* conf, int* counts, hipStream_t s);
-void launch_threshold_sweep(const float* conf, const unsigned char* correct, int E1, int N, const float* thr, int V,
+void launch_threshold_sweep(const double* conf, const unsigned char* correct, int E1, int N, const double* thr, int V,
                             double* acc, double* mean_exit, int* hist, hipStream_t s);
+void launch_msp_table(const double* logits, const long long* refs, int E1, int N, int K, double* conf, unsigned char* correct,
+                      hipStream_t s);
 void launch_build_value_tables(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,
                                const unsigned char* lut2, int heads, int bins1, int bins2, int n1, int n2, float inv_sqrt_d,
                                float* t1, float* tx, float* ty, hipStream_t s);

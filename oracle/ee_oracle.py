@@ -376,3 +376,28 @@ def early_exit(cfg, W, batch, exits, thresholds, temperatures=None, strategy="ra
         store = temperature_scale(store, temperatures)
     ex, pred, conf = policy_scan(store, thresholds)
     return {"exit_layer": ex, "logits": pred, "confidence": conf, "logits_store": store}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N3: multi-threshold search                                            EE/thresh.py:55-57, 184-215; EE/large_scale.py:42-96
+# ------------------------------------------------------------------------------------------------------------------
+def msp_table(logits_store: np.ndarray, references: Optional[np.ndarray] = None):
+    """CSF "msp" table (EE/thresh.py:55-57) and per-exit correctness (EE/large_scale.py:92-95)."""
+    L = np.asarray(logits_store, dtype=np.float64)
+    conf = softmax64(L, axis=-1).max(-1)
+    correct = None if references is None else (L.argmax(-1) == np.asarray(references)[None, :]).astype(np.uint8)
+    return conf, correct
+
+
+def threshold_sweep(conf: np.ndarray, correct: np.ndarray, thresholds_2d: np.ndarray):
+    """``check_2D_threshold`` + ``evaluate_exit_logits`` (EE/large_scale.py:42-43, 87-96) for every threshold vector:
+    exits = (CSF >= thr[:, None]).argmax(0); accuracy = mean(correct[exits, n]); average_exit = mean(exits)."""
+    E1, N = conf.shape
+    acc, mex, hist = [], [], []
+    idx = np.arange(N)
+    for thr in np.asarray(thresholds_2d, dtype=np.float64):
+        ex = (conf >= thr[:, None]).argmax(0)
+        acc.append(correct[ex, idx].mean())
+        mex.append(ex.mean())
+        hist.append(np.bincount(ex, minlength=E1))
+    return np.array(acc), np.array(mex), np.array(hist)

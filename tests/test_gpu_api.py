@@ -126,3 +126,63 @@ def test_input_validation_flags(pkg):
     with pytest.raises(KeyError):
         pkg.EarlyExitEngine(cfg, max_docs=2, max_text_len=48).load_weights(W)
     eng.close()
+
+
+def test_threshold_sweep_matches_reference_semantics(pkg, oracle):
+    """EE/large_scale.py flow at BASELINE config-2 size: CSF table -> percentile thresholds -> random mixtures -> exits."""
+    rng = np.random.default_rng(42)
+    E1, N, K, V, per = 7, 40000, 16, 300, 40
+    store = rng.standard_normal((E1, N, K)) * 2.0
+    refs = rng.integers(0, K, N)
+    conf_o, corr_o = oracle.msp_table(store, refs)
+    conf_d, corr_d = pkg.sweep.msp_table(store, refs)
+    np.testing.assert_allclose(conf_d.cpu().numpy(), conf_o, rtol=1e-13)
+    assert np.array_equal(corr_d.cpu().numpy(), corr_o)
+    # thresholds exactly as generate_thresholds (EE/large_scale.py:46-65): percentiles of the table itself, last row 0
+    conf = conf_d.cpu().numpy()
+    grid = np.zeros((E1, per))
+    for e in range(E1 - 1):
+        grid[e] = np.percentile(conf[e], np.linspace(0, 100, per))
+    sel = rng.integers(0, per, (V, E1))
+    thr = grid[np.arange(E1)[None, :], sel]
+    acc_o, mex_o, hist_o = oracle.threshold_sweep(conf, corr_o, thr)
+    acc, mex, hist = pkg.sweep.threshold_sweep(conf_d, corr_d, thr, want_hist=True)
+    np.testing.assert_array_equal(hist.cpu().numpy(), hist_o)            # integer outputs: bit-exact
+    np.testing.assert_allclose(acc.cpu().numpy(), acc_o, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(mex.cpu().numpy(), mex_o, rtol=0, atol=1e-12)
+    assert (hist.cpu().numpy().sum(1) == N).all()
+    # edge cases: thresholds nobody reaches -> exit 0 (numpy argmax of all-False); thresholds everybody reaches -> exit 0
+    edge = np.stack([np.full(E1, 2.0), np.zeros(E1)])
+    a2, m2, h2 = pkg.sweep.threshold_sweep(conf_d, corr_d, edge, want_hist=True)
+    assert (m2.cpu().numpy() == 0).all() and (h2.cpu().numpy()[:, 0] == N).all()
+
+
+def test_large_shape_gate_temperature_matches_oracle(pkg, oracle):
+    """BASELINE config-3 structure at reduced depth: LayoutLMv3-large widths (H=1024, 16 heads, coordinate 171 / shape
+    170 -> unaligned spatial slices), exit at every layer, gate strategy (policy sees classifier(gate input)), per-exit
+    temperatures applied before the confidence test."""
+    ee = dict(exits=[1, 2, 3], encoder_layer_strategy="gate", inference_strategy="max_confidence")
+    cfg = pkg.ModelConfig.large(num_hidden_layers=3, vocab_size=500, max_position_embeddings=66, input_size=64,
+                                intermediate_size=1024, EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=21)
+    docs = pkg.synth.make_documents(cfg, 5, seed=22, text_len=40, min_words=2)
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], strategy="gate", return_hidden_cls=True)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40)
+    eng.load_weights(W)
+    out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True,
+                      want_all=True, want_head=True, want_hidden_cls=True, validate=True)
+    np.testing.assert_allclose(out.hidden_cls.cpu().numpy(), ref["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out.head_logits.cpu().numpy(), ref["exit_logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out.all_logits.cpu().numpy(), ref["logits_store"], rtol=0, atol=1e-4)
+    temps = np.array([0.7, 1.9, 1.3, 2.5])
+    store = oracle.temperature_scale(ref["logits_store"], temps)
+    conf = oracle.softmax64(store).max(-1)
+    thr = np.zeros(4)
+    for e in range(4):
+        s = np.sort(conf[e]); k = int(np.argmax(np.diff(s))); thr[e] = 0.5 * (s[k] + s[k + 1])
+    ex, pred, cf = oracle.policy_scan(store, thr)
+    o2 = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], thresholds=thr,
+                     temperatures=temps)
+    assert np.array_equal(o2.exit_layer.cpu().numpy(), ex)
+    np.testing.assert_allclose(o2.logits.cpu().numpy(), pred, rtol=0, atol=1e-4)
+    eng.close()
