@@ -160,6 +160,14 @@ int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, in
 int ee_profile(ee_handle* h, int32_t enable);
 int ee_profile_read(ee_handle* h, int32_t idx, char* name_out, int32_t name_cap, double* total_ms, int32_t* launches);
 
+/* Micro-benchmark / unit-test hook: ONE launch of the path's GEMM kernel, Cout[M,N] = epi(A[M,K] W[N,K]^T + bias (+ resid)),
+ * epi 0 = bias, 1 = GELU(erf), 2 = + residual, 3 = tanh; all pointers dev float; N % 128 == 0, K % 32 == 0.
+ * wgs_per_cu sizes the persistent grid (0 = default).  row_src (dev int32 [M] or NULL) gathers the A (and residual) rows as
+ * the layer after an exit stage does.  clk_probe (dev, 2 x grid uint64, or NULL): per workgroup
+ * {shader cycles, 100 MHz real-time ticks} spent in the kernel, i.e. the clock the chip held (diagnostic). */
+int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
+                  int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream);
+
 /* Host-only helper (no GPU needed): the relative_position_bucket LUT (HF modeling_layoutlmv3.py:392-413) over
  * delta in [-max_delta, max_delta]; out_host has 2*max_delta+1 entries, index = delta + max_delta.  Exposed so the LUT
  * the kernels use can be pinned against the HF-generated golden table. */

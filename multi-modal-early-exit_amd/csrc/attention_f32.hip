@@ -31,6 +31,7 @@ constexpr int D = 64;          // head dim (base and large)
 constexpr int KSTR = 68;       // padded K row stride (floats): 16 lanes of a ds_read_b128 group on distinct slots
 constexpr int VSTR = 64;
 constexpr float kMasked = -3.0e38f;
+constexpr float kLog2e = 1.44269504088896340736f;
 
 static __host__ __device__ inline size_t attn_lds_floats(int n1, int n2) {
     return (size_t)2 * KT * KSTR + (size_t)2 * KT * VSTR + (size_t)2 * KT * 4 + (size_t)n1 + 2 * (size_t)n2;
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
             for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qp + 8 * g);
         }
         const RowMeta mq = a.meta[qrow];
+        // RowMeta carries pos/x0/y1 pre-multiplied by 4 (byte offsets into the float tables): one integer add per lookup
+        const char* t1q = reinterpret_cast<const char*>(T1 + a.c1) - mq.pos;
+        const char* txq = reinterpret_cast<const char*>(TX + a.c2) - mq.x0;
+        const char* tyq = reinterpret_cast<const char*>(TY + a.c2) - mq.y1;
 
         // staging: K tile and V tile are each 32 rows x 16 float4 = 512 float4 -> 2 per thread per operand
         const int st_row = tid >> 4;                   // 0..15 (+16)
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
             if (tid < KT) {
                 const int kr = k0 + tid;
                 if (kr < len) rm = a.meta[off + kr];
-                else rm = RowMeta{0, 0, 0, 0};
+                else rm = RowMeta{0, 0, 0, __float_as_int(kMasked)};
             }
         };
         auto store_tile = [&](int buf) {
@@ -143,26 +148,30 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
                     for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c], qf[g][c], s, 0, 0, 0);
                 }
                 // ---- bias, mask, online softmax.  register e <-> key (e&3) + 8*(e>>2) + 4*hh of the tile ---------
+                // per score: one broadcast ds_read_b128 (key metadata), three integer adds, three table reads, four
+                // float adds.  Invalid keys carry kbias = -3e38 (additive mask, EE/models/LayoutLMv3.py:622-624).
                 float tmax = kMasked;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = (e & 3) + 8 * (e >> 2) + 4 * hh;
                     const RowMeta mk = Ms[buf * KT + kl];
-                    const float b1 = T1[mk.pos - mq.pos + a.c1];
-                    const float bx = TX[mk.x0 - mq.x0 + a.c2];
-                    const float by = TY[mk.y1 - mq.y1 + a.c2];
+                    const float b1 = *reinterpret_cast<const float*>(t1q + mk.pos);
+                    const float bx = *reinterpret_cast<const float*>(txq + mk.x0);
+                    const float by = *reinterpret_cast<const float*>(tyq + mk.y1);
                     const float bias = b1 + (bx + by);              // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455
-                    const float v = (mk.flags & 1) ? (s[e] + bias) : kMasked;
+                    const float v = (s[e] + bias) + __int_as_float(mk.flags);
                     s[e] = v;
                     tmax = fmaxf(tmax, v);
                 }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float m_new = fmaxf(m_run, tmax);
-                const float alpha = expf(m_run - m_new);
+                // exp(x) = 2^(x log2 e) on v_exp_f32; x = s - m <= 0, the product is rounded once (relative error of p
+                // <= 4e-8 |x log2 e|, i.e. < 1e-6 for every weight above 1e-7)
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
                 float psum = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p = expf(s[e] - m_new);
+                    const float p = __builtin_amdgcn_exp2f((s[e] - m_new) * kLog2e);
                     s[e] = p;
                     psum += p;
                 }

@@ -761,4 +761,30 @@ int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, in
     return 0;
 }
 
+// ---- debug / micro-benchmark hooks: run ONE kernel of the path on caller-provided device buffers ------------------------
+int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
+                  int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream) {
+    if (!A || !W || !Cout || M < 1 || N % 128 || K % 32 || epi < 0 || epi > 3) return fail(nullptr, "ee_debug_gemm: bad argument");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(nullptr, "ee_debug_gemm: no device");
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.bias = bias; g.C = Cout; g.ldc = N; g.resid = resid; g.ldr = N; g.m_static = M; g.N = N; g.K = K;
+    g.scale = 1.f;
+    g.clk_probe = (unsigned long long*)clk_probe;
+    g.row_src = row_src;
+    g.resid_row_src = row_src;
+    if (epi == EPI_RESID && !resid) return fail(nullptr, "ee_debug_gemm: residual epilogue without a residual");
+    if (wgs_per_cu < 0) {   // diagnostic: stamped build, |wgs_per_cu| workgroups per CU, 8 uint64 per workgroup in clk_probe
+        launch_gemm_f32_stamped(g, epi, -wgs_per_cu * prop.multiProcessorCount, reinterpret_cast<hipStream_t>(stream));
+    } else {
+        set_gemm_wgs_per_cu(wgs_per_cu > 0 ? wgs_per_cu : 2);
+        launch_gemm_f32(g, epi, AMODE_ROWS, M, prop.multiProcessorCount, reinterpret_cast<hipStream_t>(stream));
+        set_gemm_wgs_per_cu(2);
+    }
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_debug_gemm: launch failed");
+    return 0;
+}
+
 }  // extern "C"

@@ -28,7 +28,15 @@ constexpr int STAGE_FLOATS = (BM + BN) * LDS_STRIDE;
 
 size_t gemm_f32_lds_bytes() { return 2 * STAGE_FLOATS * sizeof(float); }
 
-template <int EPI, int AMODE>
+#define STAMP(var)                                                        \
+    if (STAMPS) {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                \
+        var = __builtin_amdgcn_s_memtime();                               \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               \
+        __builtin_amdgcn_sched_barrier(0);                                \
+    }
+
+template <int EPI, int AMODE, bool STAMPS = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int M = g.m_ptr ? *g.m_ptr : g.m_static;
@@ -44,47 +52,52 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
     const int ld_row = tid >> 3;          // 0..31
     const int ld_c4 = (tid & 7) * 4;      // float column inside the BK slab
 
+    unsigned long long clk0 = 0, rt0 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    unsigned long long acc_issue = 0, acc_comp = 0, acc_store = 0, acc_bar = 0, acc_pro = 0, acc_epi = 0;
+    if (g.clk_probe) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- per-thread source pointers of the 4 A rows and 4 W rows this thread stages -------------------------
+        // Rows past M are clamped to the last valid row (their results are never stored): unconditional loads keep
+        // the staging code free of exec-mask branches and of the conservative vmcnt waits hipcc puts around them.
         const float* a_ptr[4];
-        bool a_ok[4];
         const float* w_ptr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = m0 + ld_row + 32 * i;
-            a_ok[i] = r < M;
+            int r = m0 + ld_row + 32 * i;
+            r = r < M ? r : M - 1;
             if (AMODE == AMODE_ROWS) {
-                const int src = a_ok[i] ? (g.row_src ? g.row_src[r] : r) : 0;
+                const int src = g.row_src ? g.row_src[r] : r;
                 a_ptr[i] = g.A + (size_t)src * g.lda + ld_c4;
             } else {
-                const int rr = a_ok[i] ? r : 0;
                 const int np = g.G * g.G;
-                const int b = rr / np, p = rr - b * np;
+                const int b = r / np, p = r - b * np;
                 const int py = p / g.G, px = p - py * g.G;
-                a_ptr[i] = g.pix + (size_t)b * g.C_in * g.R * g.R + (size_t)(py * g.P) * g.R + px * g.P;
+                // k = ld_c4 + k0 with k0 a multiple of 32: c = k / P^2, ky = (k % P^2) / P, kx = k % P; kx is fixed
+                a_ptr[i] = g.pix + (size_t)b * g.C_in * g.R * g.R + (size_t)(py * g.P) * g.R + px * g.P + (ld_c4 % g.P);
             }
             w_ptr[i] = g.W + (size_t)(n0 + ld_row + 32 * i) * g.K + ld_c4;
         }
 
         f32x4 ra[4], rw[4];
         auto load_stage = [&](int k0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (AMODE == AMODE_ROWS) {
-                    ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(a_ptr[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    const int k = k0 + ld_c4;
-                    const int pp = g.P * g.P;
-                    const int c = k / pp, rem = k - c * pp;
-                    const int ky = rem / g.P, kx = rem - ky * g.P;
-                    const float* p = a_ptr[i] + (size_t)c * g.R * g.R + ky * g.R + kx;
-                    ra[i] = a_ok[i] ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k0);
+            size_t a_off;
+            if (AMODE == AMODE_ROWS) {
+                a_off = (size_t)k0;
+            } else {
+                const int k = k0 + ld_c4;
+                const int pp = g.P * g.P;
+                const int c = k / pp, rem = k - c * pp;
+                const int ky = rem / g.P;
+                a_off = (size_t)c * g.R * g.R + (size_t)ky * g.R;
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + a_off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k0);
         };
         auto store_stage = [&](int buf) {
             float* As = smem + buf * STAGE_FLOATS;
@@ -104,13 +117,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        STAMP(ts0);
         load_stage(0);
         store_stage(0);
         __syncthreads();
+        STAMP(ts1);
+        if (STAMPS) acc_pro += ts1 - ts0;
 
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
+            STAMP(ts0);
             if (more) load_stage((kt + 1) * BK);
+            STAMP(ts1);
             const float* As = smem + (kt & 1) * STAGE_FLOATS;
             const float* Ws = As + BM * LDS_STRIDE;
             const float* a_base = As + (wr * 64 + l31) * LDS_STRIDE + 4 * hh;
@@ -130,33 +148,75 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][c], wf[1][c], acc[1][1], 0, 0, 0);
                 }
             }
+            STAMP(ts2);
             if (more) store_stage((kt + 1) & 1);
+            STAMP(ts3);
             __syncthreads();
+            STAMP(ts4);
+            if (STAMPS) { acc_issue += ts1 - ts0; acc_comp += ts2 - ts1; acc_store += ts3 - ts2; acc_bar += ts4 - ts3; }
         }
+        STAMP(ts0);
 
-        // ---- epilogue: C layout of a 32x32 MFMA tile is col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        // ---- epilogue.  C layout of a 32x32 MFMA tile: col = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
+        // lane owns one COLUMN — storing from registers is 64 scalar 4-byte store instructions per wave, and the
+        // store-issue tail then costs 4-8 stages of matrix-pipe time per tile (in-kernel stamps: 17k-33k cycles).
+        // The staging buffers are dead after the k-loop's last barrier, so each wave transposes its 64x64 sub-tile
+        // through its own 16 KB of LDS (ds_write_b32: 32 consecutive floats per half-wave, conflict-free) and leaves
+        // with whole rows: ds_read_b128 + one global_store_dwordx4 per 4 rows x 256 B (16 stores per wave, fully
+        // coalesced); bias / residual are read as float4 on the same row-contiguous layout.
+        {
+            float* stg = smem + wave * (64 * 64);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = n0 + wc * 64 + ni * 32 + l31;
-                const float bv = g.bias ? g.bias[col] : 0.f;
-                const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wr * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (row < M) {
-                        float v = (acc[mi][ni][e] + bv) * sc;
-                        if (EPI == EPI_GELU) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-                        if (EPI == EPI_TANH) v = tanhf(v);
-                        if (EPI == EPI_RESID) {
-                            const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                            v += g.resid[(size_t)rs * g.ldr + col];
-                        }
-                        g.C[(size_t)row * g.ldc + col] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        stg[r * 64 + ni * 32 + l31] = acc[mi][ni][e];
                     }
+            const int c4 = (lane & 15) * 4;                 // 4 consecutive columns of the wave's 64
+            const int col = n0 + wc * 64 + c4;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+            const float sc = (col < g.scale_cols) ? g.scale : 1.0f;      // scale_cols is a multiple of 128
+            const int rbase = m0 + wr * 64 + (lane >> 4);
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int rl = (lane >> 4) + 4 * j;
+                const int row = rbase + 4 * j;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + c4);
+                if (row < M) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float x = (v[t] + bv[t]) * sc;
+                        if (EPI == EPI_GELU) x = x * 0.5f * (1.0f + fast_erff(x * 0.70710678118654752440f));
+                        if (EPI == EPI_TANH) x = tanhf(x);
+                        v[t] = x;
+                    }
+                    if (EPI == EPI_RESID) {
+                        const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
+                        v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    }
+                    *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
                 }
             }
+        }
+        __syncthreads();      // the next tile's prologue overwrites the staging area
+        STAMP(ts1);
+        if (STAMPS) acc_epi += ts1 - ts0;
+    }
+    if (g.clk_probe && threadIdx.x == 0) {      // diagnostic only: shader clock = d(memtime) / d(memrealtime) * 100 MHz
+        const int st = STAMPS ? 8 : 2;
+        g.clk_probe[st * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+        g.clk_probe[st * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        if (STAMPS) {
+            g.clk_probe[8 * blockIdx.x + 2] = acc_issue;
+            g.clk_probe[8 * blockIdx.x + 3] = acc_comp;
+            g.clk_probe[8 * blockIdx.x + 4] = acc_store;
+            g.clk_probe[8 * blockIdx.x + 5] = acc_bar;
+            g.clk_probe[8 * blockIdx.x + 6] = acc_pro;
+            g.clk_probe[8 * blockIdx.x + 7] = acc_epi;
         }
     }
 }
@@ -173,9 +233,25 @@ static void launch_one(const GemmArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 
+static int g_gemm_wgs_per_cu = 2;
+void set_gemm_wgs_per_cu(int n) { g_gemm_wgs_per_cu = n < 1 ? 1 : n; }
+
+void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s) {
+    const size_t lds = gemm_f32_lds_bytes();
+    if (epi == EPI_GELU) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI_GELU, AMODE_ROWS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU, AMODE_ROWS, true>), dim3(grid), dim3(256), lds, s, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI_BIAS, AMODE_ROWS, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_BIAS, AMODE_ROWS, true>), dim3(grid), dim3(256), lds, s, a);
+    }
+}
+
 void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_cus, hipStream_t s) {
     const int tiles = ((max_m + BM - 1) / BM) * (a.N / BN);
-    int grid = 2 * num_cus;
+    int grid = g_gemm_wgs_per_cu * num_cus;
     if (tiles < grid) grid = tiles;
     if (grid < 1) grid = 1;
     if (amode == AMODE_IM2COL) {

@@ -8,14 +8,18 @@ namespace mmee {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Per-row metadata of the packed (ragged) sequence layout: what the in-kernel relative-position bias needs.
-//   pos   : position index used by the 1D bias = token index j for text rows, patch index v for visual rows
-//           (EE/models/LayoutLMv3.py:559-563 builds arange(T) ++ arange(197), NOT the pad-aware embedding positions)
-//   x0,y1 : bbox[...,0] and bbox[...,3] — the 2D bias buckets x0 and y1 (HF:433-434)
-//   flags : bit0 = row is a valid attention KEY (attention_mask != 0; visual rows always)
+// Per-row metadata of the packed (ragged) sequence layout: what the in-kernel relative-position bias needs, in the form
+// the attention kernel consumes directly.
+//   pos   : 4 * position index used by the 1D bias (token index j for text rows, patch index v for visual rows;
+//           EE/models/LayoutLMv3.py:559-563 builds arange(T) ++ arange(197), NOT the pad-aware embedding positions)
+//   x0,y1 : 4 * bbox[...,0] and 4 * bbox[...,3] — the 2D bias buckets x0 and y1 (HF:433-434)
+//           (the factor 4 makes the differences byte offsets into the float value tables)
+//   flags : float bits of the additive key mask: 0.0f for a valid attention KEY (attention_mask != 0; visual rows
+//           always), -3e38f for a masked one (EE/models/LayoutLMv3.py:622-624 adds finfo.min)
 struct RowMeta {
     int pos, x0, y1, flags;
 };
+constexpr float kKeyMasked = -3.0e38f;
 
 // Device-resident description of one exit stage (documents still active when the stage starts).
 struct StageCounts {
@@ -85,6 +89,25 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&x)[NV], int H, int lane, 
 
 constexpr int kMaxNV = 4;  // hidden_size <= 1024, multiple of 4
 
+// erf for the GELU epilogue: erf(x) = sign(x) * (1 - 2^(-q(|x|))), q = degree-8 polynomial fitted to -log2(erfc(t)) on
+// [0, 4] with the error weighted by erfc (so it is the ABSOLUTE error of erf that is minimised).  Evaluated in float32:
+// max |erf error| 1.03e-7, GELU max abs error 5.0e-7 against float64 (an exactly rounded float32 erf gives 4.5e-7), at
+// ~14 instructions instead of the ~50 of the library erff, which was 60 % of the FFN-up epilogue (in-kernel stamps).
+__device__ __forceinline__ float fast_erff(float x) {
+    const float a = fminf(fabsf(x), 4.0f);
+    float q = 5.389074067e-05f;
+    q = fmaf(q, a, -5.102792056e-04f);
+    q = fmaf(q, a, 1.682463451e-03f);
+    q = fmaf(q, a, 4.861298949e-04f);
+    q = fmaf(q, a, -2.802465111e-02f);
+    q = fmaf(q, a, 1.483877152e-01f);
+    q = fmaf(q, a, 9.184340239e-01f);
+    q = fmaf(q, a, 1.627907515e+00f);
+    q = q * a;
+    const float r = 1.0f - __builtin_amdgcn_exp2f(-q);
+    return copysignf(r, x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // launch parameter blocks
 // ---------------------------------------------------------------------------------------------------------------
@@ -110,6 +133,7 @@ struct GemmArgs {
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;
+    unsigned long long* clk_probe;   // diagnostic (ee_debug_gemm): per workgroup {shader cycles, 100 MHz ticks}; null in the path
 };
 
 struct AttnArgs {
@@ -133,6 +157,8 @@ struct AttnArgs {
 void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_cus, hipStream_t s);
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 size_t gemm_f32_lds_bytes();
+void set_gemm_wgs_per_cu(int n);
+void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s);   // diagnostic build with in-kernel stamps
 size_t attention_f32_lds_bytes(const AttnArgs& a);
 
 }  // namespace mmee

@@ -130,26 +130,27 @@ __global__ __launch_bounds__(256) void row_meta_kernel(PrepArgs a) {
         const int dst = a.text_dst[(size_t)b * T + j];
         if (dst >= 0) {
             RowMeta m;
-            m.pos = j;
+            m.pos = 4 * j;
             long long x0 = a.bbox[((size_t)b * T + j) * 4 + 0], y1 = a.bbox[((size_t)b * T + j) * 4 + 3];
-            m.x0 = (int)(x0 < 0 ? 0 : (x0 > hi ? hi : x0));
-            m.y1 = (int)(y1 < 0 ? 0 : (y1 > hi ? hi : y1));
-            m.flags = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0 ? 1 : 0) : 1;
+            m.x0 = 4 * (int)(x0 < 0 ? 0 : (x0 > hi ? hi : x0));
+            m.y1 = 4 * (int)(y1 < 0 ? 0 : (y1 > hi ? hi : y1));
+            const bool valid = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0) : true;
+            m.flags = __float_as_int(valid ? 0.0f : kKeyMasked);
             a.meta[off + dst] = m;
         }
     }
     for (int v = tid; v < a.Pv; v += 256) {
         RowMeta m;
-        m.pos = v;
+        m.pos = 4 * v;
         if (v == 0) {                      // cls_token_box = [1, 1, max_len-1, max_len-1]  (HF:594)
-            m.x0 = 1;
-            m.y1 = 999;
+            m.x0 = 4 * 1;
+            m.y1 = 4 * 999;
         } else {                           // create_visual_bbox (HF:575-596): trunc(1000*k / grid)
             const int p = v - 1, py = p / a.G, px = p - py * a.G;
-            m.x0 = (1000 * px) / a.G;
-            m.y1 = (1000 * (py + 1)) / a.G;
+            m.x0 = 4 * ((1000 * px) / a.G);
+            m.y1 = 4 * ((1000 * (py + 1)) / a.G);
         }
-        m.flags = 1;
+        m.flags = __float_as_int(0.0f);
         a.meta[off + nt + v] = m;
     }
 }
