@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--thresholds", default="", help="comma list of per-exit thresholds: skip the calibration pass (used for "
+                    "rocprofv3 runs so that every forward in the process is an identical step)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -96,9 +98,12 @@ def main():
     d_px = torch.from_numpy(docs["pixel_values"]).to(dev)
 
     # ---- threshold calibration on the resident batch (untimed): dump-all pass -> confidences -> global threshold ----
-    out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows)
-    conf = out.all_crit.cpu().numpy().astype(np.float64)
-    thr = calibrate_thresholds(conf, a.release)
+    if a.thresholds:
+        thr = np.array([float(x) for x in a.thresholds.split(",")] + [2.0])[:len(EXIT_LAYERS) + 1]
+    else:
+        out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows)
+        conf = out.all_crit.cpu().numpy().astype(np.float64)
+        thr = calibrate_thresholds(conf, a.release)
     if world > 1:                       # every rank uses rank 0's thresholds
         t = torch.from_numpy(thr).to(dev)
         dist.broadcast(t, 0)

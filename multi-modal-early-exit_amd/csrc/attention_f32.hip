@@ -34,16 +34,22 @@ constexpr float kMasked = -3.0e38f;
 constexpr float kLog2e = 1.44269504088896340736f;
 
 static __host__ __device__ inline size_t attn_lds_floats(int n1, int n2) {
-    return (size_t)2 * KT * KSTR + (size_t)2 * KT * VSTR + (size_t)2 * KT * 4 + (size_t)n1 + 2 * (size_t)n2;
+    return (size_t)KT * KSTR + (size_t)KT * VSTR + (size_t)KT * 4 + (size_t)n1 + 2 * (size_t)n2;
 }
 size_t attention_f32_lds_bytes(const AttnArgs& a) { return attn_lds_floats(a.n1, a.n2) * sizeof(float); }
 
-__global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a) {
+// LDS per workgroup: one K tile, one V tile, key metadata and the head's three value tables (38 KB at T = 512), so
+// three workgroups share a CU: the softmax of one wave (a long dependent LDS/VALU chain between its two MFMA bursts —
+// in-kernel stamps put it at 5.5k of a wave-tile's 14k cycles) overlaps the MFMA bursts of the two other waves on its
+// SIMD.  The next tile is prefetched into registers while the current one is consumed; two barriers per tile hand the
+// single LDS buffer over.  (A double-buffered variant at 2 workgroups/CU and an in-wave software pipeline
+// QK(t+1) || softmax(t) were both measured slower: 68 vs 74 TFLOP/s.)
+__global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                                  // [2][KT][KSTR]
-    float* Vs = Ks + 2 * KT * KSTR;                    // [2][KT][VSTR]
-    RowMeta* Ms = reinterpret_cast<RowMeta*>(Vs + 2 * KT * VSTR);   // [2][KT]
-    float* T1 = reinterpret_cast<float*>(Ms + 2 * KT);
+    float* Ks = smem;                                  // [KT][KSTR]
+    float* Vs = Ks + KT * KSTR;                        // [KT][VSTR]
+    RowMeta* Ms = reinterpret_cast<RowMeta*>(Vs + KT * VSTR);   // [KT]
+    float* T1 = reinterpret_cast<float*>(Ms + KT);
     float* TX = T1 + a.n1;
     float* TY = TX + a.n2;
 
@@ -113,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
                 else rm = RowMeta{0, 0, 0, __float_as_int(kMasked)};
             }
         };
-        auto store_tile = [&](int buf) {
+        auto store_tile = [&]() {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<f32x4*>(Ks + (buf * KT + st_row + 16 * i) * KSTR + st_c4) = rk[i];
-                *reinterpret_cast<f32x4*>(Vs + (buf * KT + st_row + 16 * i) * VSTR + st_c4) = rv[i];
+                *reinterpret_cast<f32x4*>(Ks + (st_row + 16 * i) * KSTR + st_c4) = rk[i];
+                *reinterpret_cast<f32x4*>(Vs + (st_row + 16 * i) * VSTR + st_c4) = rv[i];
             }
-            if (tid < KT) Ms[buf * KT + tid] = rm;
+            if (tid < KT) Ms[tid] = rm;
         };
 
         float m_run = kMasked, l_run = 0.f;
@@ -129,18 +135,17 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
 
         const int n_kt = (len + KT - 1) / KT;
         load_tile(0);
-        store_tile(0);
+        store_tile();
         __syncthreads();
         for (int kt = 0; kt < n_kt; ++kt) {
             const bool more = kt + 1 < n_kt;
             if (more) load_tile((kt + 1) * KT);
-            const int buf = kt & 1;
             if (wave_active) {
                 // ---- S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q registers) -------
                 f32x16 s;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] = 0.f;
-                const float* kb = Ks + (buf * KT + l31) * KSTR + 4 * hh;
+                const float* kb = Ks + l31 * KSTR + 4 * hh;
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + 8 * g);
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const RowMeta mk = Ms[buf * KT + kl];
+                    const RowMeta mk = Ms[kl];
                     const float b1 = *reinterpret_cast<const float*>(t1q + mk.pos);
                     const float bx = *reinterpret_cast<const float*>(txq + mk.x0);
                     const float by = *reinterpret_cast<const float*>(tyq + mk.y1);
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
                 // ---- O^T += V^T P^T : A operand = V^T (lane row = d), B operand = P^T (lane col = query) ---------
-                const float* vb = Vs + (buf * KT + 4 * hh) * VSTR + l31;
+                const float* vb = Vs + (4 * hh) * VSTR + l31;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = (e & 3) + 8 * (e >> 2);
@@ -190,8 +195,11 @@ __global__ __launch_bounds__(256, 2) void attention_f32_kernel(const AttnArgs a)
                     o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], o1, 0, 0, 0);
                 }
             }
-            if (more) store_tile((kt + 1) & 1);
-            __syncthreads();
+            if (more) {
+                __syncthreads();                       // every wave is done reading tile kt
+                store_tile();
+                __syncthreads();
+            }
         }
 
         if (wave_active) {
@@ -222,7 +230,7 @@ void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStrea
     }
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
-    int grid = 2 * num_cus;
+    int grid = 3 * num_cus;
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(attention_f32_kernel, dim3(grid), dim3(256), lds, s, a);
