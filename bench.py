@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--thresholds", default="", help="comma list of per-exit thresholds: skip the calibration pass (used for "
                     "rocprofv3 runs so that every forward in the process is an identical step)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (HBM traffic)")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
@@ -69,6 +70,44 @@ def calibrate_thresholds(conf, release):
         thr[e] = 0.5 * (c[j - 1] + c[j])
         active &= ~(conf[e] > thr[e])
     return thr
+
+
+def measure_hbm_traffic(thr, batch, kernel_substr="gemm_f32_kernel<1, 0", timeout=240):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM section)
+    prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (TCC slots), both in KiB; on gfx950
+    FETCH_SIZE reports half of the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact for
+    16-byte-per-lane stores.  Each pass is a child process running one identical step of this script.  Returns
+    (bytes_per_launch, detail) or (None, reason)."""
+    import csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mmee_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic",
+               "--batch", str(batch), "--thresholds", ",".join(repr(float(t)) for t in thr[:-1])]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            f = [os.path.join(dp, x) for dp, _, fs in os.walk(d) for x in fs if x.endswith("counter_collection.csv")]
+            tot, n = 0.0, 0
+            for row in csv.DictReader(open(f[0])):
+                if row["Counter_Name"] == ctr and kernel_substr in row["Kernel_Name"]:
+                    tot += float(row["Counter_Value"]); n += 1
+            if not n:
+                return None, f"{ctr}: kernel not found in the counter file"
+            vals[ctr] = tot / n
+        except Exception as e:  # noqa: BLE001
+            return None, f"{ctr} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return b, {"FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB": vals["WRITE_SIZE"],
+               "correction": "gfx950: FETCH_SIZE x2 (wide coalesced reads), WRITE_SIZE exact"}
 
 
 def main():
@@ -185,6 +224,14 @@ def main():
         tot = sum(v["ms"] for v in prof.values())
         line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
         fl2 = eng.flops()
+        if world == 1 and not a.no_traffic:
+            tb, detail = measure_hbm_traffic(thr, B)
+            line["roofline"]["traffic"] = tb
+            line["roofline"]["traffic_detail"] = detail
+            if tb:
+                # algorithmic HBM bytes of the same launches: read A (rows x H) + W once, write rows x I
+                alg = sum(4.0 * (r * H + r * I) for r in rows) / max(1, up["launches"]) + 4.0 * H * I
+                line["roofline"]["algorithmic_hbm_bytes_per_launch"] = alg
         line["gemm_class_tflops"] = fl2["gemm"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
         line["attention_tflops"] = fl2["attention"] / (prof["attention"]["ms"] * 1e-3) / 1e12 if prof["attention"]["ms"] else None
 

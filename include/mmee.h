@@ -152,6 +152,18 @@ int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, i
 int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, int32_t N, int32_t K, double* conf,
                  uint8_t* correct, void* stream);
 
+/*
+ * Per-exit temperature fit on the device (TemperatureScaler.set_temperature, EE/generic_scaling.py:64-111, as driven per
+ * exit by calibrate(), EE/eval.py:313-337): for every exit e, T[e] = argmin_T mean NLL(softmax(logits[e] / T), labels),
+ * starting from T = 1, by Newton iterations on 1/T (the objective is convex in 1/T).  logits dev double (E1,N,K),
+ * labels dev int64 (N,) with values in [0,K).  Outputs dev (E1,): temperature; optional nll / accuracy /
+ * avg_confidence of the scaled logits and the iteration count.  The ECE that calibrate() also records comes from a
+ * remote metric (evaluate.load("jordyvl/ece"), EE/metrics.py:479-498) that is not available offline and is not built.
+ */
+int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, int32_t N, int32_t K, int32_t max_iter,
+                       double* temperature, double* nll, double* accuracy, double* avg_confidence, int32_t* iterations,
+                       void* stream);
+
 /* Per-kernel timing of subsequent ee_forward calls with HIP events recorded on the launch stream (adds two event
  * records per launch; keep it off in timed runs).  ee_profile(h, 1) arms it and clears old records; every ee_forward
  * replaces the records.  ee_profile_read synchronises the device and returns, for kernel role idx = 0,1,..., the

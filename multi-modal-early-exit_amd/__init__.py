@@ -14,3 +14,4 @@ from .policy import Policy, policy_scan_device  # noqa: F401,E402
 from . import harness  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from . import sweep  # noqa: F401,E402
+from . import calibration  # noqa: F401,E402

@@ -65,6 +65,7 @@ SYMBOLS = {
     "ee_threshold_sweep": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ee_msp_table": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ee_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ee_temperature_fit": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ee_bucket_lut": (C.c_int, [_i32, _i32, _i32, _vp]),
     "ee_profile": (C.c_int, [_vp, _i32]),
     "ee_profile_read": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),

@@ -761,6 +761,17 @@ int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, in
     return 0;
 }
 
+int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, int32_t N, int32_t K, int32_t max_iter,
+                       double* temperature, double* nll, double* accuracy, double* avg_confidence, int32_t* iterations, void* stream) {
+    if (!logits || !labels || !temperature || E1 < 1 || N < 1 || K < 2) return fail(nullptr, "ee_temperature_fit: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_temperature_fit: no HIP device");
+    launch_temperature_fit(logits, (const long long*)labels, E1, N, K, max_iter > 0 ? max_iter : 100, temperature, nll, accuracy,
+                           avg_confidence, iterations, reinterpret_cast<hipStream_t>(stream));
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_temperature_fit: launch failed");
+    return 0;
+}
+
 // ---- debug / micro-benchmark hooks: run ONE kernel of the path on caller-provided device buffers ------------------------
 int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream) {

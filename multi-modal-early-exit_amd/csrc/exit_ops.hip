@@ -341,6 +341,95 @@ void launch_msp_table(const double* logits, const long long* refs, int E1, int N
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Per-exit temperature fit: argmin_T mean NLL(softmax(z / T), y)   (TemperatureScaler.set_temperature,
+// EE/generic_scaling.py:64-111, L-BFGS-B on sklearn log_loss).  In beta = 1/T the objective
+//     f(beta) = mean( logsumexp(beta z) - beta z_y )
+// is convex with f' = mean(E_p[z] - z_y) and f'' = mean(Var_p[z]) (p = softmax(beta z)), so a safeguarded Newton
+// iteration converges in a handful of steps; one workgroup per exit keeps the whole loop on the device.
+// Also returns the quantities calibrate() derives from the scaled logits (EE/eval.py:313-337): NLL, accuracy
+// (argmax == label) and mean max-softmax confidence at the fitted temperature.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline void block_sum3(double& a, double& b, double& c, double* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+        c += __shfl_xor(c, o, 64);
+    }
+    __syncthreads();
+    if (lane == 0) { lds[3 * wave] = a; lds[3 * wave + 1] = b; lds[3 * wave + 2] = c; }
+    __syncthreads();
+    a = b = c = 0.0;
+    for (int w = 0; w < nw; ++w) { a += lds[3 * w]; b += lds[3 * w + 1]; c += lds[3 * w + 2]; }
+}
+
+__global__ __launch_bounds__(1024) void temperature_fit_kernel(const double* __restrict__ logits, const long long* __restrict__ labels,
+                                                               int N, int K, int max_iter, double* __restrict__ T_out,
+                                                               double* __restrict__ nll_out, double* __restrict__ acc_out,
+                                                               double* __restrict__ conf_out, int* __restrict__ iters_out) {
+    __shared__ double red[3 * 16];
+    const int e = blockIdx.x;
+    const double* L = logits + (size_t)e * N * K;
+    double beta = 1.0;                                    // TemperatureScaler starts from T = 1 (generic_scaling.py:42-46)
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        double g = 0.0, h = 0.0, f = 0.0;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            const double* z = L + (size_t)n * K;
+            double m = z[0];
+            for (int k = 1; k < K; ++k) m = fmax(m, z[k]);
+            double S = 0.0, A = 0.0, B = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double w = exp(beta * (z[k] - m));
+                S += w; A += w * z[k]; B += w * z[k] * z[k];
+            }
+            A /= S; B /= S;
+            const double zy = z[labels[n]];
+            g += A - zy;
+            h += B - A * A;
+            f += log(S) + beta * (m - zy);
+        }
+        block_sum3(g, h, f, red);
+        g /= N; h /= N;
+        double step = (h > 1e-300) ? g / h : (g > 0 ? 0.5 * beta : -beta);
+        double nb = beta - step;
+        if (!(nb > 0.0)) nb = 0.5 * beta;                 // stay in beta > 0 (the reference bounds T in (1e-32, inf))
+        if (nb > 64.0 * beta) nb = 64.0 * beta;
+        const bool done = fabs(nb - beta) <= 1e-13 * beta;
+        beta = nb;
+        if (done) break;
+    }
+    // final statistics at the fitted temperature
+    double f = 0.0, acc = 0.0, conf = 0.0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double* z = L + (size_t)n * K;
+        double m = z[0];
+        int am = 0;
+        for (int k = 1; k < K; ++k)
+            if (z[k] > m) { m = z[k]; am = k; }
+        double S = 0.0;
+        for (int k = 0; k < K; ++k) S += exp(beta * (z[k] - m));
+        f += log(S) + beta * (m - z[labels[n]]);
+        acc += (am == (int)labels[n]) ? 1.0 : 0.0;
+        conf += 1.0 / S;
+    }
+    block_sum3(f, acc, conf, red);
+    if (threadIdx.x == 0) {
+        T_out[e] = 1.0 / beta;
+        if (nll_out) nll_out[e] = f / N;
+        if (acc_out) acc_out[e] = acc / N;
+        if (conf_out) conf_out[e] = conf / N;
+        if (iters_out) iters_out[e] = it;
+    }
+}
+
+void launch_temperature_fit(const double* logits, const long long* labels, int E1, int N, int K, int max_iter, double* T_out,
+                            double* nll_out, double* acc_out, double* conf_out, int* iters_out, hipStream_t s) {
+    hipLaunchKernelGGL(temperature_fit_kernel, dim3(E1), dim3(1024), 0, s, logits, labels, N, K, max_iter, T_out, nll_out,
+                       acc_out, conf_out, iters_out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // value tables of the relative-position bias: t[h][delta + c] = W[h][lut[delta + c]] / sqrt(d)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void build_value_tables_kernel(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,

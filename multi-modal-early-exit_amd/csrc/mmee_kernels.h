@@ -102,6 +102,8 @@ void launch_threshold_sweep(const double* conf, const unsigned char* correct, in
                             double* acc, double* mean_exit, int* hist, hipStream_t s);
 void launch_msp_table(const double* logits, const long long* refs, int E1, int N, int K, double* conf, unsigned char* correct,
                       hipStream_t s);
+void launch_temperature_fit(const double* logits, const long long* labels, int E1, int N, int K, int max_iter, double* T_out,
+                            double* nll_out, double* acc_out, double* conf_out, int* iters_out, hipStream_t s);
 void launch_build_value_tables(const float* w1, const float* wx, const float* wy, const unsigned char* lut1,
                                const unsigned char* lut2, int heads, int bins1, int bins2, int n1, int n2, float inv_sqrt_d,
                                float* t1, float* tx, float* ty, hipStream_t s);

@@ -401,3 +401,22 @@ def threshold_sweep(conf: np.ndarray, correct: np.ndarray, thresholds_2d: np.nda
         mex.append(ex.mean())
         hist.append(np.bincount(ex, minlength=E1))
     return np.array(acc), np.array(mex), np.array(hist)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N4: temperature fit                                                              EE/generic_scaling.py:64-111
+# ------------------------------------------------------------------------------------------------------------------
+def nll_at_temperature(logits: np.ndarray, labels: np.ndarray, T: float) -> float:
+    z = np.asarray(logits, dtype=np.float64) / T
+    z = z - z.max(-1, keepdims=True)
+    lse = np.log(np.exp(z).sum(-1))
+    return float((lse - z[np.arange(len(labels)), labels]).mean())
+
+
+def fit_temperature(logits: np.ndarray, labels: np.ndarray) -> float:
+    """``TemperatureScaler.set_temperature``: L-BFGS-B on the mean NLL of softmax(logits / T) from T = 1, bounds (1e-32, inf)
+    (sklearn.log_loss equals this NLL up to its probability clipping)."""
+    from scipy.optimize import minimize
+    r = minimize(lambda t: nll_at_temperature(logits, labels, float(t[0])), x0=np.ones(1), method="L-BFGS-B",
+                 bounds=[(1e-32, None)], options={"ftol": 1e-15, "gtol": 1e-10})
+    return float(r.x[0])

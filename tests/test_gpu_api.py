@@ -186,3 +186,33 @@ def test_large_shape_gate_temperature_matches_oracle(pkg, oracle):
     assert np.array_equal(o2.exit_layer.cpu().numpy(), ex)
     np.testing.assert_allclose(o2.logits.cpu().numpy(), pred, rtol=0, atol=1e-4)
     eng.close()
+
+
+def test_temperature_fit_matches_lbfgs_and_is_optimal(pkg, oracle):
+    rng = np.random.default_rng(9)
+    E1, N, K = 4, 4000, 16
+    labels = rng.integers(0, K, N)
+    base = rng.standard_normal((1, N, K))
+    base[:, np.arange(N), labels] += 1.5                          # informative logits
+    base = np.repeat(base, E1, axis=0)
+    scale = np.array([0.4, 1.0, 2.5, 6.0])[:, None, None]         # under- to over-confident exits
+    logits = base * scale
+    res = pkg.calibration.fit_temperatures(logits, labels)
+    for e in range(E1):
+        t_ref = oracle.fit_temperature(logits[e], labels)
+        assert abs(res["temperature"][e] - t_ref) <= 2e-4 * t_ref, (e, res["temperature"][e], t_ref)
+        # first-order optimality of OUR temperature (size-independent property): NLL is flat to second order
+        T = res["temperature"][e]
+        f0 = oracle.nll_at_temperature(logits[e], labels, T)
+        assert f0 <= oracle.nll_at_temperature(logits[e], labels, T * 1.01) and f0 <= oracle.nll_at_temperature(logits[e], labels, T / 1.01)
+        np.testing.assert_allclose(res["nll"][e], f0, rtol=1e-10)
+        z = logits[e] / T
+        np.testing.assert_allclose(res["accuracy"][e], (z.argmax(-1) == labels).mean(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(res["average_confidence"][e], oracle.softmax64(z).max(-1).mean(), rtol=1e-10)
+    assert (res["iterations"] < 40).all()
+    # the exits differ only by a scale, so the fitted temperatures do too
+    np.testing.assert_allclose(res["temperature"] / scale.ravel(), res["temperature"][1], rtol=1e-6)
+    ts = pkg.calibration.TemperatureScaler()
+    ts.fit(labels, logits[2])
+    np.testing.assert_allclose(ts.temperature[0], res["temperature"][2], rtol=1e-12)
+    np.testing.assert_allclose(ts.temperature_scale(logits[2]), logits[2] / res["temperature"][2])
