@@ -17,7 +17,7 @@ FLAG_NO_EXIT = 2
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _LIB_NAME = "libmmee_hip.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+_LIB_PATH = os.environ.get("MMEE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 class MMEEUnavailable(RuntimeError):

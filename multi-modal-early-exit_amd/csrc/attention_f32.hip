@@ -34,7 +34,7 @@ constexpr float kMasked = -3.0e38f;
 constexpr float kLog2e = 1.44269504088896340736f;
 
 static __host__ __device__ inline size_t attn_lds_floats(int n1, int n2) {
-    return (size_t)KT * KSTR + (size_t)KT * VSTR + (size_t)KT * 4 + (size_t)n1 + 2 * (size_t)n2;
+    return (size_t)KT * KSTR + (size_t)KT * VSTR + (size_t)KT * 4 + (size_t)n1 + 2 * (size_t)n2 + 4;   // + work-queue slot
 }
 size_t attention_f32_lds_bytes(const AttnArgs& a) { return attn_lds_floats(a.n1, a.n2) * sizeof(float); }
 
@@ -60,7 +60,17 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
     const int n_items = n_docs * a.heads * qtiles;
     int cur_head = -1;
 
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // work items (document, head, 128-query tile) differ a lot in cost (ragged lengths): hand them out dynamically
+    int* q_slot = reinterpret_cast<int*>(TY + a.n2);
+    int item = blockIdx.x;
+    for (;; item += gridDim.x) {
+        if (a.item_counter) {
+            __syncthreads();                           // everyone has read the previous slot value
+            if (tid == 0) *q_slot = atomicAdd(a.item_counter, 1);
+            __syncthreads();
+            item = *q_slot;
+        }
+        if (item >= n_items) break;
         const int doc = item / (a.heads * qtiles);
         const int rem = item - doc * (a.heads * qtiles);
         const int head = rem / qtiles, qt = rem - head * qtiles;

@@ -62,6 +62,8 @@ struct ee_handle {
     // workspace
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
     int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
+    int* queue_heads = nullptr;                   // one work-queue counter per persistent launch of a forward
+    int n_queue_heads = 0, next_queue_head = 0;
     RowMeta* meta[2];
     int *doc_orig, *doc_off, *x_src, *meta_src;   // [(E+2)][max_docs+1]
     StageCounts* counts;                          // [(E+2)]
@@ -346,6 +348,8 @@ int ee_create(const ee_config* c, ee_handle** out) {
         rc |= dev_alloc(h, &h->ntext, Bm);
         rc |= dev_alloc(h, &h->row_src, rows);
         rc |= dev_alloc(h, &h->err_flag, 4);
+        h->n_queue_heads = 8 * L + 4 * (E + 1) + 16;
+        rc |= dev_alloc(h, &h->queue_heads, (size_t)h->n_queue_heads);
         rc |= dev_alloc(h, &h->meta[0], rows);
         rc |= dev_alloc(h, &h->meta[1], rows);
         const size_t st = (size_t)(E + 2) * (Bm + 1);
@@ -506,6 +510,11 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     auto S_meta_src = [&](int st) { return h->meta_src + st * sstride; };
 
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
+    HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
+    h->next_queue_head = 0;
+    auto next_head = [&]() -> int* {
+        return h->next_queue_head < h->n_queue_heads ? h->queue_heads + h->next_queue_head++ : nullptr;
+    };
     if (h->prof_on) { h->prof_recs.clear(); h->prof_used = 0; }
     bool need[3] = {false, false, false};
     for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
@@ -542,6 +551,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
     pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
     pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
+    pg.tile_counter = next_head();
     { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
 
     EmbedArgs va = ea;
@@ -571,7 +581,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (hw.dense_w) {
             GemmArgs g{};
             g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
-            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f;
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
             launch_gemm_f32(g, EPI_TANH, AMODE_ROWS, B, cus, s);
             hin = hid; hld = H; hg = nullptr;
         }
@@ -639,26 +649,26 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         GemmArgs g{};
         // QKV projection, Q pre-divided by sqrt(d) (HF:263)
         g.A = h->X; g.lda = H; g.row_src = rs; g.W = w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
-        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f;
+        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head();
         { ProfScope ps(h, P_GQKV, s); launch_gemm_f32(g, EPI_BIAS, AMODE_ROWS, max_rows, cus, s); }
         AttnArgs at{};
         at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
         at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
-        at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len;
+        at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
         { ProfScope ps(h, P_ATTN, s); launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
-        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f;
+        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
         { ProfScope ps(h, P_GAO, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
         { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
         // FFN (HF:485-512)
         g = GemmArgs{};
-        g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f;
+        g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
         { ProfScope ps(h, P_GUP, s); launch_gemm_f32(g, EPI_GELU, AMODE_ROWS, max_rows, cus, s); }
         g = GemmArgs{};
         g.A = h->H1; g.lda = I; g.W = w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
-        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f;
+        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head();
         { ProfScope ps(h, P_GDOWN, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
         { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
         // the layer wrote X densely in the numbering of stage `cur`
@@ -775,7 +785,7 @@ int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, 
 // ---- debug / micro-benchmark hooks: run ONE kernel of the path on caller-provided device buffers ------------------------
 int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream) {
-    if (!A || !W || !Cout || M < 1 || N % 128 || K % 32 || epi < 0 || epi > 3) return fail(nullptr, "ee_debug_gemm: bad argument");
+    if (!A || !W || !Cout || M < 1 || N % 128 || K % 32 || epi < 0 || (epi & 15) > 3) return fail(nullptr, "ee_debug_gemm: bad argument");
     hipDeviceProp_t prop;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -784,15 +794,20 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
     g.A = A; g.lda = K; g.W = W; g.bias = bias; g.C = Cout; g.ldc = N; g.resid = resid; g.ldr = N; g.m_static = M; g.N = N; g.K = K;
     g.scale = 1.f;
     g.clk_probe = (unsigned long long*)clk_probe;
+    static int* dbg_head = nullptr;
+    if (!dbg_head && hipMalloc((void**)&dbg_head, 64) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
+    if (hipMemsetAsync(dbg_head, 0, 64, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
+    g.tile_counter = (epi & 16) ? nullptr : dbg_head;    // epi | 16 = static grid stride (A/B switch)
+    epi &= 15;
     g.row_src = row_src;
     g.resid_row_src = row_src;
     if (epi == EPI_RESID && !resid) return fail(nullptr, "ee_debug_gemm: residual epilogue without a residual");
     if (wgs_per_cu < 0) {   // diagnostic: stamped build, |wgs_per_cu| workgroups per CU, 8 uint64 per workgroup in clk_probe
         launch_gemm_f32_stamped(g, epi, -wgs_per_cu * prop.multiProcessorCount, reinterpret_cast<hipStream_t>(stream));
     } else {
-        set_gemm_wgs_per_cu(wgs_per_cu > 0 ? wgs_per_cu : 2);
+        set_gemm_wgs_per_cu(wgs_per_cu);
         launch_gemm_f32(g, epi, AMODE_ROWS, M, prop.multiProcessorCount, reinterpret_cast<hipStream_t>(stream));
-        set_gemm_wgs_per_cu(2);
+        set_gemm_wgs_per_cu(0);
     }
     if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_debug_gemm: launch failed");
     return 0;

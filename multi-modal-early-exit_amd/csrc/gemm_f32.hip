@@ -23,10 +23,23 @@
 
 namespace mmee {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDS_STRIDE = 36;
+#ifndef MMEE_GEMM_BK
+#define MMEE_GEMM_BK 32
+#endif
+constexpr int BM = 128, BN = 128, BK = MMEE_GEMM_BK, LDS_STRIDE = BK + 4;
 constexpr int STAGE_FLOATS = (BM + BN) * LDS_STRIDE;
+constexpr int LD_TPR = BK / 4;              // threads per staged row (one float4 each)
+constexpr int LD_RPP = 256 / LD_TPR;        // rows per staging pass
+constexpr int LD_NP = BM / LD_RPP;          // passes per operand
+constexpr int GEMM_WGS = (BK == 16) ? 3 : 2;   // workgroups per CU the LDS / register budget is sized for
+constexpr size_t EPI_STAGE_FLOATS = 4 * 32 * 64;   // epilogue transpose: 4 waves x 32 rows x 64 cols
 
-size_t gemm_f32_lds_bytes() { return 2 * STAGE_FLOATS * sizeof(float); }
+constexpr size_t LOOP_LDS_FLOATS = 2 * (size_t)STAGE_FLOATS;
+constexpr size_t MAIN_LDS_FLOATS = LOOP_LDS_FLOATS > EPI_STAGE_FLOATS ? LOOP_LDS_FLOATS : EPI_STAGE_FLOATS;
+
+// + 16 bytes at the end of the dynamic region for the work-queue slot (a static __shared__ object would shift the
+// dynamic base off its 16-byte alignment, cdna_hip_programming.md Guideline 17)
+size_t gemm_f32_lds_bytes() { return MAIN_LDS_FLOATS * sizeof(float) + 16; }
 
 #define STAMP(var)                                                        \
     if (STAMPS) {                                                         \
@@ -37,7 +50,7 @@ size_t gemm_f32_lds_bytes() { return 2 * STAGE_FLOATS * sizeof(float); }
     }
 
 template <int EPI, int AMODE, bool STAMPS = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int M = g.m_ptr ? *g.m_ptr : g.m_static;
     const int tiles_m = (M + BM - 1) / BM;
@@ -49,25 +62,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int ld_row = tid >> 3;          // 0..31
-    const int ld_c4 = (tid & 7) * 4;      // float column inside the BK slab
+    const int ld_row = tid / LD_TPR;             // row inside a staging pass
+    const int ld_c4 = (tid % LD_TPR) * 4;        // float column inside the BK slab
 
     unsigned long long clk0 = 0, rt0 = 0;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
     unsigned long long acc_issue = 0, acc_comp = 0, acc_store = 0, acc_bar = 0, acc_pro = 0, acc_epi = 0;
     if (g.clk_probe) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // Tiles are handed out by an atomic work-queue counter (zeroed by the host before the launch) instead of a static
+    // grid stride: workgroups run at slightly different speeds (cache / fabric position), and with ~87 tiles each the
+    // static split left the average workgroup idle for 6.7 % of the kernel waiting for the slowest one.
+    int* q_slot = reinterpret_cast<int*>(smem + MAIN_LDS_FLOATS);
+    int tile = blockIdx.x;
+    for (;; tile += gridDim.x) {
+        if (g.tile_counter) {
+            if (tid == 0) *q_slot = atomicAdd(g.tile_counter, 1);
+            __syncthreads();
+            tile = *q_slot;
+        }
+        if (tile >= n_tiles) break;
         const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- per-thread source pointers of the 4 A rows and 4 W rows this thread stages -------------------------
         // Rows past M are clamped to the last valid row (their results are never stored): unconditional loads keep
         // the staging code free of exec-mask branches and of the conservative vmcnt waits hipcc puts around them.
-        const float* a_ptr[4];
-        const float* w_ptr[4];
+        const float* a_ptr[LD_NP];
+        const float* w_ptr[LD_NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = m0 + ld_row + 32 * i;
+        for (int i = 0; i < LD_NP; ++i) {
+            int r = m0 + ld_row + LD_RPP * i;
             r = r < M ? r : M - 1;
             if (AMODE == AMODE_ROWS) {
                 const int src = g.row_src ? g.row_src[r] : r;
@@ -79,10 +103,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
                 // k = ld_c4 + k0 with k0 a multiple of 32: c = k / P^2, ky = (k % P^2) / P, kx = k % P; kx is fixed
                 a_ptr[i] = g.pix + (size_t)b * g.C_in * g.R * g.R + (size_t)(py * g.P) * g.R + px * g.P + (ld_c4 % g.P);
             }
-            w_ptr[i] = g.W + (size_t)(n0 + ld_row + 32 * i) * g.K + ld_c4;
+            w_ptr[i] = g.W + (size_t)(n0 + ld_row + LD_RPP * i) * g.K + ld_c4;
         }
 
-        f32x4 ra[4], rw[4];
+        f32x4 ra[LD_NP], rw[LD_NP];
         auto load_stage = [&](int k0) {
             size_t a_off;
             if (AMODE == AMODE_ROWS) {
@@ -95,17 +119,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
                 a_off = (size_t)c * g.R * g.R + (size_t)ky * g.R;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + a_off);
+            for (int i = 0; i < LD_NP; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + a_off);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k0);
+            for (int i = 0; i < LD_NP; ++i) rw[i] = *reinterpret_cast<const f32x4*>(w_ptr[i] + k0);
         };
         auto store_stage = [&](int buf) {
             float* As = smem + buf * STAGE_FLOATS;
             float* Ws = As + BM * LDS_STRIDE;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f32x4*>(As + (ld_row + 32 * i) * LDS_STRIDE + ld_c4) = ra[i];
-                *reinterpret_cast<f32x4*>(Ws + (ld_row + 32 * i) * LDS_STRIDE + ld_c4) = rw[i];
+            for (int i = 0; i < LD_NP; ++i) {
+                *reinterpret_cast<f32x4*>(As + (ld_row + LD_RPP * i) * LDS_STRIDE + ld_c4) = ra[i];
+                *reinterpret_cast<f32x4*>(Ws + (ld_row + LD_RPP * i) * LDS_STRIDE + ld_c4) = rw[i];
             }
         };
 
@@ -165,40 +189,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
         // with whole rows: ds_read_b128 + one global_store_dwordx4 per 4 rows x 256 B (16 stores per wave, fully
         // coalesced); bias / residual are read as float4 on the same row-contiguous layout.
         {
-            float* stg = smem + wave * (64 * 64);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int r = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        stg[r * 64 + ni * 32 + l31] = acc[mi][ni][e];
-                    }
+            float* stg = smem + wave * (32 * 64);           // 8 KB per wave, one 32-row half of its sub-tile at a time
             const int c4 = (lane & 15) * 4;                 // 4 consecutive columns of the wave's 64
             const int col = n0 + wc * 64 + c4;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
             const float sc = (col < g.scale_cols) ? g.scale : 1.0f;      // scale_cols is a multiple of 128
-            const int rbase = m0 + wr * 64 + (lane >> 4);
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int rl = (lane >> 4) + 4 * j;
-                const int row = rbase + 4 * j;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + c4);
-                if (row < M) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float x = (v[t] + bv[t]) * sc;
-                        if (EPI == EPI_GELU) x = x * 0.5f * (1.0f + fast_erff(x * 0.70710678118654752440f));
-                        if (EPI == EPI_TANH) x = tanhf(x);
-                        v[t] = x;
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        stg[r * 64 + ni * 32 + l31] = acc[mi][ni][e];
                     }
-                    if (EPI == EPI_RESID) {
-                        const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                        v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                const int rbase = m0 + wr * 64 + mi * 32 + (lane >> 4);
+#pragma unroll 4
+                for (int j = 0; j < 8; ++j) {
+                    const int rl = (lane >> 4) + 4 * j;
+                    const int row = rbase + 4 * j;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + c4);
+                    if (row < M) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float x = (v[t] + bv[t]) * sc;
+                            if (EPI == EPI_GELU) x = x * 0.5f * (1.0f + fast_erff(x * 0.70710678118654752440f));
+                            if (EPI == EPI_TANH) x = tanhf(x);
+                            v[t] = x;
+                        }
+                        if (EPI == EPI_RESID) {
+                            const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
+                            v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                        }
+                        *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
                     }
-                    *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
                 }
             }
         }
@@ -233,8 +258,8 @@ static void launch_one(const GemmArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 
-static int g_gemm_wgs_per_cu = 2;
-void set_gemm_wgs_per_cu(int n) { g_gemm_wgs_per_cu = n < 1 ? 1 : n; }
+static int g_gemm_wgs_per_cu = 0;   // 0 = the tile configuration's own choice
+void set_gemm_wgs_per_cu(int n) { g_gemm_wgs_per_cu = n < 0 ? 0 : n; }
 
 void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s) {
     const size_t lds = gemm_f32_lds_bytes();
@@ -251,7 +276,7 @@ void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s
 
 void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_cus, hipStream_t s) {
     const int tiles = ((max_m + BM - 1) / BM) * (a.N / BN);
-    int grid = g_gemm_wgs_per_cu * num_cus;
+    int grid = (g_gemm_wgs_per_cu > 0 ? g_gemm_wgs_per_cu : GEMM_WGS) * num_cus;
     if (tiles < grid) grid = tiles;
     if (grid < 1) grid = 1;
     if (amode == AMODE_IM2COL) {

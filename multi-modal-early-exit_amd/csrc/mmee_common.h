@@ -133,6 +133,7 @@ struct GemmArgs {
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;
+    int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
     unsigned long long* clk_probe;   // diagnostic (ee_debug_gemm): per workgroup {shader cycles, 100 MHz ticks}; null in the path
 };
 
@@ -149,6 +150,7 @@ struct AttnArgs {
     const float* ty;             // [heads][n2]
     int n1, c1, n2, c2;
     int H, heads, max_len;
+    int* item_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
 };
 
 // ---------------------------------------------------------------------------------------------------------------
