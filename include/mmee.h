@@ -164,6 +164,24 @@ int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, 
                        double* temperature, double* nll, double* accuracy, double* avg_confidence, int32_t* iterations,
                        void* stream);
 
+/*
+ * Device-side input feed (replaces the host image processor + collator in front of the model, EE/data/RVL_CDIP.py:246-262
+ * and EE/utils.py:93-98, 173).
+ *
+ * ee_preprocess_images: B raw page images -> pixel_values (B,3,R,R) float32.  `images` dev uint8: the images packed back to
+ *   back, each HWC RGB (c = 3) or HW greyscale (c = 1, replicated to 3 channels like Image.convert("RGB")); `desc` dev array
+ *   of B records {int64 offset; int32 h, w, c, pad}.  Resize = Pillow Image.resize(BILINEAR) bit for bit, then HF rescale
+ *   (1/255) and normalise (mean = std = 0.5).  in/out size ratio must be <= 31.  `workspace` dev scratch of
+ *   ee_preprocess_workspace_bytes(B, R, max_h) bytes (max_h = largest image height).  resized_u8 (B,R,R,3) optional.
+ * ee_collate_pad: ragged token streams (ids dev int64 [total], boxes dev int64 [total,4], offsets dev int64 [B+1]) ->
+ *   max_length tensors (B,T): input_ids padded with pad_id, attention_mask, bbox padded with zeros; longer inputs truncated.
+ */
+int ee_preprocess_images(const uint8_t* images, const void* desc, int32_t B, int32_t R, int32_t max_h, void* workspace,
+                         size_t workspace_bytes, float* pixel_values, uint8_t* resized_u8, void* stream);
+size_t ee_preprocess_workspace_bytes(int32_t B, int32_t R, int32_t max_h);
+int ee_collate_pad(const int64_t* ids, const int64_t* boxes, const int64_t* offsets, int32_t B, int32_t T, int64_t pad_id,
+                   int64_t* out_ids, int64_t* out_mask, int64_t* out_bbox, void* stream);
+
 /* Per-kernel timing of subsequent ee_forward calls with HIP events recorded on the launch stream (adds two event
  * records per launch; keep it off in timed runs).  ee_profile(h, 1) arms it and clears old records; every ee_forward
  * replaces the records.  ee_profile_read synchronises the device and returns, for kernel role idx = 0,1,..., the

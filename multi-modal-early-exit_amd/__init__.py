@@ -15,3 +15,4 @@ from . import harness  # noqa: F401,E402
 from . import dist  # noqa: F401,E402
 from . import sweep  # noqa: F401,E402
 from . import calibration  # noqa: F401,E402
+from . import feed  # noqa: F401,E402

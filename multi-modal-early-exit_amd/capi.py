@@ -66,6 +66,9 @@ SYMBOLS = {
     "ee_msp_table": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ee_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ee_temperature_fit": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ee_preprocess_images": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "ee_preprocess_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),
+    "ee_collate_pad": (C.c_int, [_vp, _vp, _vp, _i32, _i32, C.c_int64, _vp, _vp, _vp, _vp]),
     "ee_bucket_lut": (C.c_int, [_i32, _i32, _i32, _vp]),
     "ee_profile": (C.c_int, [_vp, _i32]),
     "ee_profile_read": (C.c_int, [_vp, _i32, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),

@@ -782,6 +782,51 @@ int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, 
     return 0;
 }
 
+// ---- device-side input feed (N2) ----------------------------------------------------------------------------------------
+int ee_preprocess_images(const uint8_t* images, const void* desc, int32_t B, int32_t R, int32_t max_h, void* workspace,
+                         size_t workspace_bytes, float* pixel_values, uint8_t* resized_u8, void* stream) {
+    constexpr int KMAX = 64;
+    if (!images || !desc || !workspace || !pixel_values || B < 1 || R < 1 || max_h < 1) return fail(nullptr, "ee_preprocess_images: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_preprocess_images: no HIP device");
+    // workspace layout: lut[256] f32 | bounds[B*2*R] int2 | kk[B*2*R*KMAX] int | tmp[B*max_h*R*3] u8
+    const size_t o_lut = 0, o_b = 1024, o_k = o_b + sizeof(int2) * (size_t)B * 2 * R;
+    const size_t o_t = (o_k + sizeof(int) * (size_t)B * 2 * R * KMAX + 255) & ~(size_t)255;
+    const size_t need = o_t + (size_t)B * max_h * R * 3;
+    if (workspace_bytes < need) return fail(nullptr, "ee_preprocess_images: workspace needs %zu bytes", need);
+    char* ws = static_cast<char*>(workspace);
+    float lut[256];
+    for (int u = 0; u < 256; ++u) {              // HF rescale (float64 product -> float32) then normalize in float32
+        const float v = (float)((double)u * (1.0 / 255.0));
+        lut[u] = (v - 0.5f) / 0.5f;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(ws + o_lut, lut, sizeof(lut), hipMemcpyHostToDevice, s) != hipSuccess) return fail(nullptr, "ee_preprocess_images: lut copy failed");
+    launch_preprocess_images(images, static_cast<const ImageDesc*>(desc), B, R, KMAX, max_h, reinterpret_cast<int2*>(ws + o_b),
+                             reinterpret_cast<int*>(ws + o_k), reinterpret_cast<unsigned char*>(ws + o_t),
+                             reinterpret_cast<const float*>(ws + o_lut), pixel_values, resized_u8, s);
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_preprocess_images: launch failed");
+    return 0;
+}
+
+size_t ee_preprocess_workspace_bytes(int32_t B, int32_t R, int32_t max_h) {
+    constexpr int KMAX = 64;
+    const size_t o_b = 1024, o_k = o_b + sizeof(int2) * (size_t)B * 2 * R;
+    const size_t o_t = (o_k + sizeof(int) * (size_t)B * 2 * R * KMAX + 255) & ~(size_t)255;
+    return o_t + (size_t)B * max_h * R * 3;
+}
+
+int ee_collate_pad(const int64_t* ids, const int64_t* boxes, const int64_t* offsets, int32_t B, int32_t T, int64_t pad_id,
+                   int64_t* out_ids, int64_t* out_mask, int64_t* out_bbox, void* stream) {
+    if (!ids || !boxes || !offsets || !out_ids || !out_mask || !out_bbox || B < 1 || T < 1) return fail(nullptr, "ee_collate_pad: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_collate_pad: no HIP device");
+    launch_collate_pad((const long long*)ids, (const long long*)boxes, (const long long*)offsets, B, T, pad_id,
+                       (long long*)out_ids, (long long*)out_mask, (long long*)out_bbox, reinterpret_cast<hipStream_t>(stream));
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_collate_pad: launch failed");
+    return 0;
+}
+
 // ---- debug / micro-benchmark hooks: run ONE kernel of the path on caller-provided device buffers ------------------------
 int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream) {

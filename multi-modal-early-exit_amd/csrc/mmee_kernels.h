@@ -84,6 +84,15 @@ struct DecideArgs {
     float* out_head_crit;            // (E,B)
 };
 
+struct ImageDesc {
+    long long offset;                // byte offset of the image inside the packed uint8 buffer (HWC, or HW when c == 1)
+    int h, w, c, pad;
+};
+
+void launch_preprocess_images(const unsigned char* images, const ImageDesc* desc, int B, int R, int KMAX, int max_h, int2* bounds,
+                              int* kk, unsigned char* tmp, const float* lut, float* out, unsigned char* out_u8, hipStream_t s);
+void launch_collate_pad(const long long* ids, const long long* boxes, const long long* offsets, int B, int T, long long pad_id,
+                        long long* out_ids, long long* out_mask, long long* out_bbox, hipStream_t s);
 void launch_prep(const PrepArgs& a, hipStream_t s);
 void launch_embed_text(const EmbedArgs& a, hipStream_t s);
 void launch_embed_visual(const EmbedArgs& a, hipStream_t s);

@@ -135,3 +135,15 @@ def make_documents(cfg: ModelConfig, n_docs: int, seed: int = 1234, text_len: in
     if labels:
         out["labels"] = rng.integers(0, cfg.num_labels, size=n_docs).astype(np.int64)
     return out
+
+
+def make_page_image(seed: int, h: int, w: int, channels: int = 1) -> np.ndarray:
+    """Synthetic raw page (uint8, (h,w) greyscale or (h,w,3)): white paper, dark strokes, sensor noise — the input of the
+    device-side preprocessing (RVL-CDIP pages are greyscale scans of at most 1000 px)."""
+    rng = np.random.default_rng(seed)
+    a = np.full((h, w, channels), 255, np.uint8)
+    for _ in range(40):
+        y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+        a[y0:y0 + int(rng.integers(1, 6)), x0:x0 + int(rng.integers(5, 120))] = int(rng.integers(0, 90))
+    a = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    return a[:, :, 0] if channels == 1 else a

@@ -420,3 +420,85 @@ def fit_temperature(logits: np.ndarray, labels: np.ndarray) -> float:
     r = minimize(lambda t: nll_at_temperature(logits, labels, float(t[0])), x0=np.ones(1), method="L-BFGS-B",
                  bounds=[(1e-32, None)], options={"ftol": 1e-15, "gtol": 1e-10})
     return float(r.x[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N2: image preprocessing                     LayoutLMv3 image processor as the reference calls it (EE/data/RVL_CDIP.py:246-262)
+# ------------------------------------------------------------------------------------------------------------------
+# Third-party boundary: Pillow's Image.resize(resample=BILINEAR) (libImaging/Resample.c), called by the HF LayoutLMv3
+# image processor the reference constructs at EE/models/LayoutLMv3.py:674-677.  Pillow is not vendored by the reference;
+# the algorithm below is Resample.c's 8-bit path (precompute_coeffs / normalize_coeffs_8bpc /
+# ImagingResampleHorizontal_8bpc / Vertical_8bpc) and is pinned against Pillow 12.2 outputs in tests/golden/preprocess.npz.
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Per output index: (xmin, xmax, int32 weights[ksize]) exactly as precompute_coeffs + normalize_coeffs_8bpc."""
+    scale = in_size / out_size                     # double, in0 = 0, in1 = in_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale                    # bilinear filter support = 1
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = np.zeros(ksize, dtype=np.float64)
+        ww = 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            a = -a if a < 0.0 else a
+            v = 1.0 - a if a < 1.0 else 0.0
+            w[x] = v
+            ww += v
+        if ww != 0.0:
+            w[:xmax] = w[:xmax] / ww
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + w[x] * (1 << _PRECISION_BITS)) if w[x] < 0 else int(0.5 + w[x] * (1 << _PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_bilinear_resize_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """img (H,W,C) uint8 -> (out_h,out_w,C) uint8: horizontal pass then vertical pass, each rounded to 8 bits
+    (ImagingResample with both passes needed; a pass whose size does not change is skipped, as in Resample.c)."""
+    img = np.asarray(img, dtype=np.uint8)
+    H, W, C = img.shape
+    cur = img
+    if W != out_w:
+        b, kk = pil_bilinear_coeffs(W, out_w)
+        tmp = np.zeros((H, out_w, C), dtype=np.uint8)
+        for xx in range(out_w):
+            xmin, xmax = b[xx]
+            acc = (cur[:, xmin:xmin + xmax, :].astype(np.int64) * kk[xx, :xmax][None, :, None]).sum(1) + (1 << (_PRECISION_BITS - 1))
+            tmp[:, xx, :] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+        cur = tmp
+    if H != out_h:
+        b, kk = pil_bilinear_coeffs(H, out_h)
+        tmp = np.zeros((out_h, cur.shape[1], C), dtype=np.uint8)
+        for yy in range(out_h):
+            ymin, ymax = b[yy]
+            acc = (cur[ymin:ymin + ymax, :, :].astype(np.int64) * kk[yy, :ymax][:, None, None]).sum(0) + (1 << (_PRECISION_BITS - 1))
+            tmp[yy] = np.clip(acc >> _PRECISION_BITS, 0, 255)
+        cur = tmp
+    return cur
+
+
+def rescale_normalize_lut() -> np.ndarray:
+    """uint8 -> float32 exactly as HF rescale (uint8 * (1/255) in float64, cast to float32) then normalize with
+    mean = std = 0.5 in float32 (IMAGENET_STANDARD_MEAN/STD of the LayoutLMv3 image processor)."""
+    v = (np.arange(256, dtype=np.uint8) * (1 / 255)).astype(np.float32)
+    return ((v - np.float32(0.5)) / np.float32(0.5)).astype(np.float32)
+
+
+def preprocess_image(img: np.ndarray, size: int = 224) -> np.ndarray:
+    """(H,W,3) uint8 RGB -> (3,size,size) float32 pixel_values."""
+    r = pil_bilinear_resize_u8(img, size, size)
+    return rescale_normalize_lut()[r].transpose(2, 0, 1).copy()

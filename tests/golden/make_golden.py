@@ -201,5 +201,25 @@ def main():
     print("policy_random done")
 
 
+PREPROCESS_SHAPES = [(1000, 762, 1), (100, 150, 1), (224, 224, 3), (300, 224, 1), (333, 1000, 3)]
+
+
+def make_preprocess_golden():
+    """Pillow's own Image.resize(BILINEAR) on synthetic pages (down-, up-scaling, identity, greyscale and RGB); the pages
+    are rebuilt from their seeds by synth.make_page_image, the fixture holds Pillow's 224x224 outputs."""
+    from PIL import Image
+    out = {"shapes": np.array(PREPROCESS_SHAPES)}
+    for i, (h, w, c) in enumerate(PREPROCESS_SHAPES):
+        a = pkg.synth.make_page_image(100 + i, h, w, c)
+        img = Image.fromarray(a).convert("RGB")
+        out[f"res{i}"] = np.asarray(img.resize((224, 224), resample=Image.BILINEAR))
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+    print("preprocess golden done")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
+        make_preprocess_golden()
+    else:
+        main()
+        make_preprocess_golden()

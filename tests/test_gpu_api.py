@@ -216,3 +216,40 @@ def test_temperature_fit_matches_lbfgs_and_is_optimal(pkg, oracle):
     ts.fit(labels, logits[2])
     np.testing.assert_allclose(ts.temperature[0], res["temperature"][2], rtol=1e-12)
     np.testing.assert_allclose(ts.temperature_scale(logits[2]), logits[2] / res["temperature"][2])
+
+
+def test_device_preprocessing_is_bit_exact_with_pillow(pkg, oracle):
+    g = load_golden("preprocess")
+    imgs = [pkg.synth.make_page_image(100 + i, int(h), int(w), int(c)) for i, (h, w, c) in enumerate(g["shapes"])]
+    px, u8 = pkg.feed.preprocess_images(imgs, 224, return_u8=True)
+    lut = oracle.rescale_normalize_lut()
+    for i in range(len(imgs)):
+        assert np.array_equal(u8[i].cpu().numpy(), g[f"res{i}"]), i                     # uint8 resize: bit-exact
+        np.testing.assert_array_equal(px[i].cpu().numpy(), lut[g[f"res{i}"]].transpose(2, 0, 1))   # float: bit-exact
+    assert px.dtype.is_floating_point and tuple(px.shape) == (len(imgs), 3, 224, 224)
+
+
+def test_device_collation_and_feeder(pkg):
+    import torch
+    rng = np.random.default_rng(4)
+    samples = []
+    for i in range(7):
+        n = int(rng.integers(3, 60)) if i != 3 else 600                      # one over-long document: truncated to T
+        samples.append({"image": pkg.synth.make_page_image(i, 200 + 10 * i, 150 + 7 * i, 1),
+                        "input_ids": [0] + list(rng.integers(3, 300, n)) + [2],
+                        "bbox": np.concatenate([[[0, 0, 0, 0]], rng.integers(0, 1000, (n, 4)), [[0, 0, 0, 0]]]), "labels": i % 4})
+    T = 512
+    ids, am, bb = pkg.feed.collate_pad([s["input_ids"] for s in samples], [s["bbox"] for s in samples], T, 1)
+    for i, s in enumerate(samples):
+        n = min(len(s["input_ids"]), T)
+        assert np.array_equal(ids[i, :n].cpu().numpy(), np.asarray(s["input_ids"][:n])) and (ids[i, n:] == 1).all()
+        assert am[i].sum().item() == n and (am[i, :n] == 1).all()
+        assert np.array_equal(bb[i, :n].cpu().numpy(), np.asarray(s["bbox"])[:n]) and (bb[i, n:] == 0).all()
+    seen = 0
+    for batch in pkg.feed.DeviceFeeder(samples, batch_size=3, max_length=T):
+        b = batch["input_ids"].shape[0]
+        ref = pkg.feed.preprocess_images([s["image"] for s in samples[seen:seen + b]], 224)
+        assert torch.equal(batch["pixel_values"], ref) and torch.equal(batch["input_ids"], ids[seen:seen + b])
+        assert batch["labels"].tolist() == [s["labels"] for s in samples[seen:seen + b]]
+        seen += b
+    assert seen == 7

@@ -76,3 +76,13 @@ def test_base_shape_matches_reference(pkg, oracle):
     for i in range(4):
         ex, pred, _ = oracle.policy_scan(out["logits_store"], float(g[f"pol_thr{i}"]))
         assert np.array_equal(ex, g[f"pol_exits{i}"])
+
+
+def test_pil_resize_restatement_matches_pillow_golden(pkg, oracle):
+    g = load_golden("preprocess")
+    for i, (h, w, c) in enumerate(g["shapes"]):
+        img = pkg.synth.make_page_image(100 + i, int(h), int(w), int(c))
+        rgb = img if img.ndim == 3 else np.repeat(img[:, :, None], 3, axis=2)
+        assert np.array_equal(oracle.pil_bilinear_resize_u8(rgb, 224, 224), g[f"res{i}"]), (h, w, c)
+    lut = oracle.rescale_normalize_lut()
+    assert lut[0] == -1.0 and lut[255] == 1.0 and lut.dtype == np.float32
