@@ -551,7 +551,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
     pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
     pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
-    pg.tile_counter = next_head();
+    pg.tile_counter = next_head(); pg.prio_mode = 1;
     { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
 
     EmbedArgs va = ea;
@@ -581,7 +581,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (hw.dense_w) {
             GemmArgs g{};
             g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
-            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
             launch_gemm_f32(g, EPI_TANH, AMODE_ROWS, B, cus, s);
             hin = hid; hld = H; hg = nullptr;
         }
@@ -649,7 +649,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         GemmArgs g{};
         // QKV projection, Q pre-divided by sqrt(d) (HF:263)
         g.A = h->X; g.lda = H; g.row_src = rs; g.W = w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
-        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head();
+        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GQKV, s); launch_gemm_f32(g, EPI_BIAS, AMODE_ROWS, max_rows, cus, s); }
         AttnArgs at{};
         at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
@@ -659,16 +659,16 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
-        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
+        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GAO, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
         { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
         // FFN (HF:485-512)
         g = GemmArgs{};
-        g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head();
+        g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GUP, s); launch_gemm_f32(g, EPI_GELU, AMODE_ROWS, max_rows, cus, s); }
         g = GemmArgs{};
         g.A = h->H1; g.lda = I; g.W = w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
-        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head();
+        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GDOWN, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
         { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
         // the layer wrote X densely in the numbering of stage `cur`
@@ -843,6 +843,8 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
     if (!dbg_head && hipMalloc((void**)&dbg_head, 64) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
     if (hipMemsetAsync(dbg_head, 0, 64, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
     g.tile_counter = (epi & 16) ? nullptr : dbg_head;    // epi | 16 = static grid stride (A/B switch)
+    g.dbg_noload = (epi & 32) ? 1 : 0;
+    g.prio_mode = (epi >> 6) & 3;                         // epi | 64 / 128: static priority variants                    // epi | 32 = no in-loop global loads (timing diagnostic)
     epi &= 15;
     g.row_src = row_src;
     g.resid_row_src = row_src;

@@ -65,6 +65,15 @@ __global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs 
     const int ld_row = tid / LD_TPR;             // row inside a staging pass
     const int ld_c4 = (tid % LD_TPR) * 4;        // float column inside the BK slab
 
+    // The two waves that share a SIMD (one from each resident workgroup) otherwise alternate MFMAs fairly, finish their
+    // 64-MFMA bursts together and then sit in their load-issue / ds_write / barrier phases together, leaving the matrix
+    // pipe idle ~10 % of the time.  A static priority for the wave in the odd hardware wave slot de-synchronises them: it
+    // owns the pipe while it computes and the other wave fills every gap; the work queue absorbs the speed difference.
+    if (g.prio_mode) {
+        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;   // HW_REG_HW_ID.WAVE_ID
+        if ((g.prio_mode == 1 && (wave_slot & 1u)) || (g.prio_mode == 2 && (blockIdx.x >= gridDim.x / 2)))
+            __builtin_amdgcn_s_setprio(1);
+    }
     unsigned long long clk0 = 0, rt0 = 0;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
     unsigned long long acc_issue = 0, acc_comp = 0, acc_store = 0, acc_bar = 0, acc_pro = 0, acc_epi = 0;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs 
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
             STAMP(ts0);
-            if (more) load_stage((kt + 1) * BK);
+            if (more && !g.dbg_noload) load_stage((kt + 1) * BK);
             STAMP(ts1);
             const float* As = smem + (kt & 1) * STAGE_FLOATS;
             const float* Ws = As + BM * LDS_STRIDE;
