@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="documents per step per GPU")
     ap.add_argument("--precision", default="fp32", choices=["fp32"])
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+                    help="config2 (default, BASELINE configs[1]): base, ramp exits every 2 layers.  config3 (BASELINE configs[2]): "
+                         "LayoutLMv3-large, gate exit at every layer, per-exit temperatures")
     ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
     ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
@@ -124,8 +127,16 @@ def main():
     torch.cuda.set_device(dev)
     pkg = importlib.import_module("multi-modal-early-exit_amd")
 
-    ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="ramp", inference_strategy="max_confidence")
-    cfg = pkg.ModelConfig.base(EE_config=ee)
+    global EXIT_LAYERS
+    temps = None
+    if a.workload == "config3":
+        EXIT_LAYERS = list(range(1, 24))
+        ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="gate", inference_strategy="max_confidence")
+        cfg = pkg.ModelConfig.large(EE_config=ee)
+        temps = np.random.default_rng(a.seed).uniform(0.5, 3.0, len(EXIT_LAYERS) + 1)
+    else:
+        ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+        cfg = pkg.ModelConfig.base(EE_config=ee)
     W = pkg.synth.make_weights(cfg, seed=a.seed, head_gain=6.0)
     B, T = a.batch, 512
     eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev)
@@ -140,7 +151,7 @@ def main():
     if a.thresholds:
         thr = np.array([float(x) for x in a.thresholds.split(",")] + [2.0])[:len(EXIT_LAYERS) + 1]
     else:
-        out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows)
+        out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows, temperatures=temps)
         conf = out.all_crit.cpu().numpy().astype(np.float64)
         thr = calibrate_thresholds(conf, a.release)
     if world > 1:                       # every rank uses rank 0's thresholds
@@ -149,7 +160,7 @@ def main():
         thr = t.cpu().numpy()
 
     def step():
-        return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows)
+        return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows, temperatures=temps)
 
     for _ in range(a.warmup):
         out = step()
@@ -180,7 +191,7 @@ def main():
 
     n_docs = gathered.shape[0]
     exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
-    layer_of_exit = np.array(EXIT_LAYERS + [cfg.num_hidden_layers])
+    layer_of_exit = np.array(list(EXIT_LAYERS) + [cfg.num_hidden_layers])
     counts = eng.stage_counts()
     fl = eng.flops()
 
@@ -188,8 +199,11 @@ def main():
         "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: LayoutLMv3-base, exits at layers 2/4/6/8/10 + final, ramp, "
-                               "per-exit max-confidence thresholds, S=512+197, synthetic RVL-CDIP-shaped docs, random-init weights",
+        "config": {"workload": ("BASELINE configs[1]: LayoutLMv3-base, exits at layers 2/4/6/8/10 + final, ramp, "
+                                "per-exit max-confidence thresholds, S=512+197, synthetic RVL-CDIP-shaped docs, random-init weights")
+                   if a.workload == "config2" else
+                   ("BASELINE configs[2]: LayoutLMv3-large, gate exit at every layer (policy sees classifier(gate input)), "
+                    "per-exit temperatures U(0.5,3), per-exit thresholds, S=512+197, synthetic docs, random-init weights"),
                    "docs_per_step_per_gpu": B, "text_len": T, "rows_layout": "dense" if a.dense_rows else "ragged",
                    "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
                    "release_fraction_per_exit": a.release},
@@ -238,28 +252,30 @@ def main():
     if rank == 0 and a.cpu_docs != 0:
         # ---- CPU baseline: the oracle = the reference's semantics (every layer, every exit, simulated policy), B=1 ---
         oracle = importlib.import_module("oracle.ee_oracle")
-        cores = min(16, os.cpu_count() or 1)        # the box's CPU share for one GPU; BLAS oversubscribes beyond it
-        try:
-            from threadpoolctl import threadpool_limits
-            threadpool_limits(limits=cores)
-        except Exception:
-            cores = os.cpu_count() or 1
+        otorch = importlib.import_module("oracle.ee_oracle_torch")
+        cores = min(16, os.cpu_count() or 1)        # the box's CPU share for one GPU
+        torch.set_num_threads(cores)
+        strat = ee["encoder_layer_strategy"]
+        tor = otorch.TorchOracle(cfg, W)
         one = {k: v[:1] for k, v in docs.items()}
+        tor.forward_all(one, ee["exits"], strategy=strat)                  # warm the thread pool / allocator
         t1 = time.perf_counter()
-        r0 = oracle.forward_all(cfg, W, one, ee["exits"])
+        r0 = tor.forward_all(one, ee["exits"], strategy=strat)
         per_doc = time.perf_counter() - t1
-        n = a.cpu_docs if a.cpu_docs > 0 else int(min(16, max(2, round(15.0 / max(per_doc, 1e-3)))))
+        n = a.cpu_docs if a.cpu_docs > 0 else int(min(32, max(2, round(15.0 / max(per_doc, 1e-3)))))
         t1 = time.perf_counter()
         stores = [r0["logits_store"]]
         for i in range(1, n):
-            stores.append(oracle.forward_all(cfg, W, {k: v[i:i + 1] for k, v in docs.items()}, ee["exits"])["logits_store"])
+            stores.append(tor.forward_all({k: v[i:i + 1] for k, v in docs.items()}, ee["exits"], strategy=strat)["logits_store"])
         store = np.concatenate(stores, axis=1)
+        if temps is not None:
+            store = oracle.temperature_scale(store, temps)
         ex_cpu, pred_cpu, _ = oracle.policy_scan(store, thr)
         cpu_dt = per_doc + (time.perf_counter() - t1)
         line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "docs/s", "cores": cores, "kind": "port",
                                 "sample": f"{n} documents of the same batch, B=1 per forward (reference default "
-                                          f"eval_batch_size=1), full depth + all exits + simulated policy, numpy/OpenBLAS "
-                                          f"float32 on {cores} host threads"}
+                                          f"eval_batch_size=1), full depth + all exits + simulated policy, torch-CPU float32 "
+                                          f"restatement (oracle/ee_oracle_torch.py) on {cores} host threads"}
         g_ex = out.exit_layer.cpu().numpy()[:n] if world == 1 else exits[:n]
         g_lg = gathered[:n, :cfg.num_labels].cpu().numpy() if world > 1 else out.logits.cpu().numpy()[:n]
         line["parity_vs_cpu_sample"] = {"docs": n, "exit_index_equal": bool(np.array_equal(g_ex, ex_cpu)),

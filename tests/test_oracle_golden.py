@@ -86,3 +86,16 @@ def test_pil_resize_restatement_matches_pillow_golden(pkg, oracle):
         assert np.array_equal(oracle.pil_bilinear_resize_u8(rgb, 224, 224), g[f"res{i}"]), (h, w, c)
     lut = oracle.rescale_normalize_lut()
     assert lut[0] == -1.0 and lut[255] == 1.0 and lut.dtype == np.float32
+
+
+def test_torch_oracle_matches_numpy_oracle(pkg, oracle):
+    import importlib
+    ot = importlib.import_module("oracle.ee_oracle_torch")
+    for name in ("tiny_ramp", "tiny_gate"):
+        g = load_golden(name)
+        ee = TINY_CASES[name]
+        cfg = pkg.ModelConfig.tiny(EE_config=ee)
+        W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+        docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+        out = ot.TorchOracle(cfg, W).forward_all(docs, ee["exits"], strategy=ee["encoder_layer_strategy"])
+        np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
