@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512, help="documents per step per GPU")
     ap.add_argument("--precision", default="fp32", choices=["fp32"])
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="config2 (default, BASELINE configs[1]): base, ramp exits every 2 layers.  config3 (BASELINE configs[2]): "
-                         "LayoutLMv3-large, gate exit at every layer, per-exit temperatures")
+                         "LayoutLMv3-large, gate exit at every layer, per-exit temperatures.  config5 (BASELINE configs[4]): "
+                         "image-only DiT-base (BEiT), ramp exit head at every layer")
     ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
     ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
@@ -134,18 +135,26 @@ def main():
         ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="gate", inference_strategy="max_confidence")
         cfg = pkg.ModelConfig.large(EE_config=ee)
         temps = np.random.default_rng(a.seed).uniform(0.5, 3.0, len(EXIT_LAYERS) + 1)
+    elif a.workload == "config5":
+        EXIT_LAYERS = list(range(1, 12))
+        ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+        cfg = pkg.ModelConfig.dit_base(EE_config=ee)
     else:
         ee = dict(exits=list(EXIT_LAYERS), encoder_layer_strategy="ramp", inference_strategy="max_confidence")
         cfg = pkg.ModelConfig.base(EE_config=ee)
-    W = pkg.synth.make_weights(cfg, seed=a.seed, head_gain=6.0)
+    beit = cfg.arch == "beit"
+    W = (pkg.synth.make_weights_beit if beit else pkg.synth.make_weights)(cfg, seed=a.seed, head_gain=6.0)
     B, T = a.batch, 512
     eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev)
     eng.load_weights(W)
-    docs = pkg.synth.make_documents(cfg, B, seed=a.seed + 1000 * rank, text_len=T)
-    d_ids = torch.from_numpy(docs["input_ids"]).to(dev)
-    d_am = torch.from_numpy(docs["attention_mask"]).to(dev)
-    d_bb = torch.from_numpy(docs["bbox"]).to(dev)
+    docs = pkg.synth.make_documents(cfg, B, seed=a.seed + 1000 * rank, text_len=T if not beit else 8)
     d_px = torch.from_numpy(docs["pixel_values"]).to(dev)
+    if beit:
+        d_ids = d_am = d_bb = None
+    else:
+        d_ids = torch.from_numpy(docs["input_ids"]).to(dev)
+        d_am = torch.from_numpy(docs["attention_mask"]).to(dev)
+        d_bb = torch.from_numpy(docs["bbox"]).to(dev)
 
     # ---- threshold calibration on the resident batch (untimed): dump-all pass -> confidences -> global threshold ----
     if a.thresholds:
@@ -203,7 +212,10 @@ def main():
                                 "per-exit max-confidence thresholds, S=512+197, synthetic RVL-CDIP-shaped docs, random-init weights")
                    if a.workload == "config2" else
                    ("BASELINE configs[2]: LayoutLMv3-large, gate exit at every layer (policy sees classifier(gate input)), "
-                    "per-exit temperatures U(0.5,3), per-exit thresholds, S=512+197, synthetic docs, random-init weights"),
+                    "per-exit temperatures U(0.5,3), per-exit thresholds, S=512+197, synthetic docs, random-init weights")
+                   if a.workload == "config3" else
+                   ("BASELINE configs[4]: image-only DiT-base (BEiT, S=197), ramp exit head at every layer (extrapolation: the "
+                    "reference defines no DiT exits), per-exit thresholds, synthetic pages, random-init weights"),
                    "docs_per_step_per_gpu": B, "text_len": T, "rows_layout": "dense" if a.dense_rows else "ragged",
                    "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
                    "release_fraction_per_exit": a.release},
@@ -256,7 +268,13 @@ def main():
         cores = min(16, os.cpu_count() or 1)        # the box's CPU share for one GPU
         torch.set_num_threads(cores)
         strat = ee["encoder_layer_strategy"]
-        tor = otorch.TorchOracle(cfg, W)
+        if beit:
+            class _B:      # numpy restatement (S = 197 is small enough for numpy)
+                def forward_all(self, b, exits, strategy="ramp"):
+                    return oracle.forward_all_beit(cfg, W, b["pixel_values"], exits, strategy=strategy)
+            tor = _B()
+        else:
+            tor = otorch.TorchOracle(cfg, W)
         one = {k: v[:1] for k, v in docs.items()}
         tor.forward_all(one, ee["exits"], strategy=strat)                  # warm the thread pool / allocator
         t1 = time.perf_counter()
@@ -274,8 +292,8 @@ def main():
         cpu_dt = per_doc + (time.perf_counter() - t1)
         line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "docs/s", "cores": cores, "kind": "port",
                                 "sample": f"{n} documents of the same batch, B=1 per forward (reference default "
-                                          f"eval_batch_size=1), full depth + all exits + simulated policy, torch-CPU float32 "
-                                          f"restatement (oracle/ee_oracle_torch.py) on {cores} host threads"}
+                                          f"eval_batch_size=1), full depth + all exits + simulated policy, "
+                                          f"{'numpy' if beit else 'torch-CPU'} float32 restatement on {cores} host threads"}
         g_ex = out.exit_layer.cpu().numpy()[:n] if world == 1 else exits[:n]
         g_lg = gathered[:n, :cfg.num_labels].cpu().numpy() if world > 1 else out.logits.cpu().numpy()[:n]
         line["parity_vs_cpu_sample"] = {"docs": n, "exit_index_equal": bool(np.array_equal(g_ex, ex_cpu)),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MMEE_ABI_VERSION 1
+#define MMEE_ABI_VERSION 2
 #define MMEE_MAX_ENCODER_EXITS 64
 
 /* embedding-level exits, in the order the reference evaluates them (EE/models/LayoutLMv3.py:465-605) */
@@ -43,6 +43,9 @@ enum { MMEE_EXIT_VISION_AVG = 0, MMEE_EXIT_TEXT_AVG = 1, MMEE_EXIT_TEXT_VISUAL_C
 enum { MMEE_STRATEGY_RAMP = 0, MMEE_STRATEGY_GATE = 1 };
 /* inference_strategy (EE/models/EE_modules.py:116-146): max_confidence exits on crit > thr, entropy on crit < thr */
 enum { MMEE_CRIT_MAX_CONFIDENCE = 0, MMEE_CRIT_ENTROPY = 1 };
+/* model family: LayoutLMv3 (text + layout + image, the reference's EE model) or BEiT / DiT (image only; BASELINE configs[4],
+ * the reference's "dit" branch EE/configs.py:429-449 — exit heads there are this build's extrapolation) */
+enum { MMEE_ARCH_LAYOUTLMV3 = 0, MMEE_ARCH_BEIT = 1 };
 /* arithmetic of the encoder GEMMs */
 enum { MMEE_PREC_F32 = 0, MMEE_PREC_BF16 = 1 };
 /* ee_load_tensor dtypes */
@@ -78,6 +81,11 @@ typedef struct ee_config {
     int32_t max_docs;                               /* largest B one ee_forward call may pass */
     int32_t max_text_len;                           /* largest T */
     int32_t precision;                              /* MMEE_PREC_* */
+    /* model family (appended in ABI version 2) */
+    int32_t arch;                                   /* MMEE_ARCH_* */
+    int32_t use_abs_pos;                            /* BEiT: use_absolute_position_embeddings */
+    int32_t layer_scale;                            /* BEiT: layer_scale_init_value > 0 (lambda_1 / lambda_2 present) */
+    int32_t use_mean_pooling;                       /* BEiT: must be 1 (DiT); pooled = LayerNorm(mean of patch tokens) */
 } ee_config;
 
 int ee_create(const ee_config* cfg, ee_handle** out);

@@ -8,7 +8,7 @@ from .config import (EarlyExitHead, EarlyExitInference, EarlyExitStrategy, ExitC
                      POSSIBLE_EXITS, parse_exits)
 from . import capi  # noqa: F401,E402
 from .engine import EarlyExitEngine, EngineOutput, load_checkpoint_tensors, save_checkpoint  # noqa: F401,E402
-from .modeling import (EEModelOutput, EESequenceClassifierOutput,  # noqa: F401,E402
+from .modeling import (DiTEEForImageClassification, EEModelOutput, EESequenceClassifierOutput,  # noqa: F401,E402
                        LayoutLMv3EEForSequenceClassification)
 from .policy import Policy, policy_scan_device  # noqa: F401,E402
 from . import harness  # noqa: F401,E402

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_ENCODER_EXITS = 64
 EXIT_KIND = {"vision_avg": 0, "text_avg": 1, "text_visual_concat": 2}
 FLAG_DENSE_ROWS = 1
@@ -44,6 +44,7 @@ class EEConfig(C.Structure):
         ("n_encoder_exits", C.c_int32), ("encoder_exit_layers", C.c_int32 * MAX_ENCODER_EXITS),
         ("exit_head_num_layers", C.c_int32), ("strategy", C.c_int32), ("criterion", C.c_int32),
         ("max_docs", C.c_int32), ("max_text_len", C.c_int32), ("precision", C.c_int32),
+        ("arch", C.c_int32), ("use_abs_pos", C.c_int32), ("layer_scale", C.c_int32), ("use_mean_pooling", C.c_int32),
     ]
 
 

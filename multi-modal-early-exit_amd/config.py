@@ -163,14 +163,30 @@ class ModelConfig:
     has_relative_attention_bias: bool = True
     has_spatial_attention_bias: bool = True
     EE_config: Dict[str, Any] = field(default_factory=dict)
+    # model family: "layoutlmv3" (the reference's EE model) or "beit" (image-only DiT, BASELINE configs[4]; the
+    # reference's "dit" branch loads a stock BEiT classifier, EE/configs.py:429-449)
+    arch: str = "layoutlmv3"
+    layer_scale_init_value: float = 0.1          # BEiT: lambda_1 / lambda_2 present when > 0
+    use_mean_pooling: bool = True                # BEiT pooler: LayerNorm(mean of patch tokens)
+    use_absolute_position_embeddings: bool = True
+    use_relative_position_bias: bool = False
+    use_shared_relative_position_bias: bool = False
 
     def __post_init__(self):
         if self.hidden_size % self.num_attention_heads:
             raise ValueError("hidden_size must be a multiple of num_attention_heads")
-        if 4 * self.coordinate_size + 2 * self.shape_size != self.hidden_size:
-            raise ValueError("4*coordinate_size + 2*shape_size must equal hidden_size (HF:112-136 concat)")
         if self.hidden_act != "gelu":
             raise ValueError("only the erf GELU of the reference checkpoints is implemented")
+        if self.arch == "beit":
+            if self.use_relative_position_bias or self.use_shared_relative_position_bias:
+                raise ValueError("BEiT relative position bias is not built (DiT uses absolute position embeddings)")
+            if not self.use_mean_pooling:
+                raise ValueError("only use_mean_pooling=True (DiT) is built")
+            return
+        if self.arch != "layoutlmv3":
+            raise ValueError(f"unknown arch {self.arch!r}")
+        if 4 * self.coordinate_size + 2 * self.shape_size != self.hidden_size:
+            raise ValueError("4*coordinate_size + 2*shape_size must equal hidden_size (HF:112-136 concat)")
         if not (self.has_relative_attention_bias and self.has_spatial_attention_bias):
             raise ValueError("the path implements the LayoutLMv3 relative + spatial attention bias")
 
@@ -210,11 +226,29 @@ class ModelConfig:
         d.update(kw)
         return cls(**d)
 
+    @classmethod
+    def dit_base(cls, **kw) -> "ModelConfig":
+        """DiT-base = BEiT-base/16 at 224 px with absolute position embeddings, layer scale 0.1, mean pooling."""
+        d = dict(arch="beit", layer_norm_eps=1e-12)
+        d.update(kw)
+        return cls(**d)
+
+    @classmethod
+    def dit_tiny(cls, **kw) -> "ModelConfig":
+        d = dict(arch="beit", layer_norm_eps=1e-12, hidden_size=128, num_hidden_layers=4, num_attention_heads=2,
+                 intermediate_size=256, input_size=64, patch_size=16)
+        d.update(kw)
+        return cls(**d)
+
     # ---- HF checkpoint-dir config.json ----------------------------------------------------------
     @classmethod
     def from_hf_dict(cls, d: Dict[str, Any]) -> "ModelConfig":
         names = {f for f in cls.__dataclass_fields__}
         kw = {k: v for k, v in d.items() if k in names}
+        if d.get("model_type") == "beit":
+            kw["arch"] = "beit"
+            if "image_size" in d:
+                kw["input_size"] = d["image_size"]
         if "num_labels" not in kw and "id2label" in d:
             kw["num_labels"] = len(d["id2label"])
         ee = d.get("EE_config") or d.get("exit_config") or {}
@@ -228,6 +262,8 @@ class ModelConfig:
 
     def to_hf_dict(self) -> Dict[str, Any]:
         d = asdict(self)
-        d["model_type"] = "layoutlmv3"
+        d["model_type"] = self.arch
+        if self.arch == "beit":
+            d["image_size"] = self.input_size
         d["id2label"] = {str(i): f"LABEL_{i}" for i in range(self.num_labels)}
         return d

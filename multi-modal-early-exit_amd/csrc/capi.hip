@@ -32,6 +32,7 @@ struct Param {
 
 struct LayerW {
     float *qkv_w, *qkv_b, *ao_w, *ao_b, *ao_g, *ao_beta, *f1_w, *f1_b, *f2_w, *f2_b, *f_g, *f_beta;
+    float *lam1 = nullptr, *lam2 = nullptr;   // BEiT layer scale (lambda_1 / lambda_2)
 };
 struct HeadW {
     float *dense_w = nullptr, *dense_b = nullptr, *out_w = nullptr, *out_b = nullptr;
@@ -239,7 +240,11 @@ int ee_create(const ee_config* c, ee_handle** out) {
     const int H = c->hidden_size, I = c->intermediate_size, L = c->num_hidden_layers, K = c->num_labels;
     if (H % 128 || I % 128 || H > 1024) return fail(nullptr, "hidden_size/intermediate_size must be multiples of 128, hidden_size <= 1024");
     if (H % c->num_attention_heads || H / c->num_attention_heads != 64) return fail(nullptr, "head dim must be 64");
-    if (4 * c->coordinate_size + 2 * c->shape_size != H) return fail(nullptr, "4*coordinate_size + 2*shape_size != hidden_size");
+    const bool beit = c->arch == MMEE_ARCH_BEIT;
+    if (c->arch != MMEE_ARCH_LAYOUTLMV3 && !beit) return fail(nullptr, "unknown arch %d", c->arch);
+    if (!beit && 4 * c->coordinate_size + 2 * c->shape_size != H) return fail(nullptr, "4*coordinate_size + 2*shape_size != hidden_size");
+    if (beit && c->n_embedding_exits) return fail(nullptr, "the BEiT / DiT variant has encoder-layer exits only");
+    if (beit && !c->use_mean_pooling) return fail(nullptr, "BEiT / DiT: only use_mean_pooling = 1 is built");
     if (c->input_size % c->patch_size || (c->num_channels * c->patch_size * c->patch_size) % 32 || c->patch_size % 4 || c->input_size % 4)
         return fail(nullptr, "unsupported patch geometry");
     if (K < 1 || K > 64) return fail(nullptr, "num_labels must be in [1,64]");
@@ -249,7 +254,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
         const int l = c->encoder_exit_layers[i];
         if (l < 1 || l > L || (i && l <= c->encoder_exit_layers[i - 1])) return fail(nullptr, "encoder_exit_layers must be ascending in [1,L]");
     }
-    if (c->max_docs < 1 || c->max_text_len < 1 || c->max_text_len > 1024) return fail(nullptr, "max_docs >= 1, 1 <= max_text_len <= 1024");
+    if (c->max_docs < 1 || c->max_text_len < (beit ? 0 : 1) || c->max_text_len > 1024) return fail(nullptr, "max_docs >= 1, 1 <= max_text_len <= 1024");
     if (c->precision != MMEE_PREC_F32) return fail(nullptr, "precision %d not built (fp32 only in this build)", c->precision);
     if (c->exit_head_num_layers != 1 && c->exit_head_num_layers != 2) return fail(nullptr, "exit_head_num_layers must be 1 or 2");
     int ndev = 0;
@@ -264,8 +269,61 @@ int ee_create(const ee_config* c, ee_handle** out) {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = prop.multiProcessorCount;
 
     // ---- parameter registry (HF names) ------------------------------------------------------------------------
-    const std::string p = "layoutlmv3.";
+    const int NP = (c->input_size / c->patch_size) * (c->input_size / c->patch_size);
+    const bool two = c->exit_head_num_layers == 2;
+    const int out_dim = c->strategy == MMEE_STRATEGY_RAMP ? K : 2;     // EE/models/LayoutLMv3.py:83
     int rc = 0;
+    h->layers.resize(L);
+    h->enc_heads.resize(c->n_encoder_exits);
+    if (beit) {
+        // BEiT / DiT (transformers 4.x parameter names, as in the DiT checkpoints the reference's "dit" branch loads,
+        // EE/configs.py:429-449).  Exit heads are this build's extrapolation: the reference has none.
+        const std::string p = "beit.";
+        rc |= add_param(h, p + "embeddings.cls_token", &h->cls_token, {1, 1, H});
+        if (c->use_abs_pos) rc |= add_param(h, p + "embeddings.position_embeddings", &h->pos_embed, {1, NP + 1, H});
+        rc |= add_param(h, p + "embeddings.patch_embeddings.projection.weight", &h->patch_w, {H, c->num_channels, c->patch_size, c->patch_size});
+        rc |= add_param(h, p + "embeddings.patch_embeddings.projection.bias", &h->patch_b, {H});
+        for (int l = 0; l < L && !rc; ++l) {
+            LayerW& w = h->layers[l];
+            const std::string q = p + "encoder.layer." + std::to_string(l) + ".";
+            rc |= dev_alloc(h, &w.qkv_w, (size_t)3 * H * H);
+            rc |= dev_alloc(h, &w.qkv_b, (size_t)3 * H);
+            if (rc) break;
+            if (hipMemset(w.qkv_b, 0, sizeof(float) * 3 * H) != hipSuccess) { rc = fail(h, "hipMemset failed"); break; }   // key has no bias
+            const char* nm[3] = {"query", "key", "value"};
+            for (int t = 0; t < 3; ++t) {
+                rc |= add_param(h, q + "attention.attention." + nm[t] + ".weight", nullptr, {H, H}, w.qkv_w + (size_t)t * H * H);
+                if (t != 1) rc |= add_param(h, q + "attention.attention." + nm[t] + ".bias", nullptr, {H}, w.qkv_b + (size_t)t * H);
+            }
+            rc |= add_param(h, q + "attention.output.dense.weight", &w.ao_w, {H, H});
+            rc |= add_param(h, q + "attention.output.dense.bias", &w.ao_b, {H});
+            rc |= add_param(h, q + "layernorm_before.weight", &w.ao_g, {H});
+            rc |= add_param(h, q + "layernorm_before.bias", &w.ao_beta, {H});
+            rc |= add_param(h, q + "intermediate.dense.weight", &w.f1_w, {I, H});
+            rc |= add_param(h, q + "intermediate.dense.bias", &w.f1_b, {I});
+            rc |= add_param(h, q + "output.dense.weight", &w.f2_w, {H, I});
+            rc |= add_param(h, q + "output.dense.bias", &w.f2_b, {H});
+            rc |= add_param(h, q + "layernorm_after.weight", &w.f_g, {H});
+            rc |= add_param(h, q + "layernorm_after.bias", &w.f_beta, {H});
+            if (c->layer_scale) {
+                rc |= add_param(h, q + "lambda_1", &w.lam1, {H});
+                rc |= add_param(h, q + "lambda_2", &w.lam2, {H});
+            }
+        }
+        if (c->use_mean_pooling) {
+            rc |= add_param(h, p + "pooler.layernorm.weight", &h->ln_g, {H});
+            rc |= add_param(h, p + "pooler.layernorm.bias", &h->ln_b, {H});
+        } else {
+            rc |= add_param(h, p + "layernorm.weight", &h->ln_g, {H});
+            rc |= add_param(h, p + "layernorm.bias", &h->ln_b, {H});
+        }
+        for (int k = 0; k < c->n_encoder_exits && !rc; ++k)
+            rc |= add_head(h, p + "encoder.early_exits." + std::to_string(k), &h->enc_heads[k], H, out_dim, two);
+        h->classifier.out_dim = K;                                     // BeitForImageClassification.classifier = Linear(H, K)
+        rc |= add_param(h, "classifier.weight", &h->classifier.out_w, {K, H});
+        rc |= add_param(h, "classifier.bias", &h->classifier.out_b, {K});
+    } else {
+    const std::string p = "layoutlmv3.";
     rc |= add_param(h, p + "embeddings.word_embeddings.weight", &h->word, {c->vocab_size, H});
     rc |= add_param(h, p + "embeddings.token_type_embeddings.weight", &h->type, {c->type_vocab_size, H});
     rc |= add_param(h, p + "embeddings.position_embeddings.weight", &h->pos, {c->max_position_embeddings, H});
@@ -277,7 +335,6 @@ int ee_create(const ee_config* c, ee_handle** out) {
     rc |= add_param(h, p + "embeddings.LayerNorm.bias", &h->emb_b, {H});
     rc |= add_param(h, p + "patch_embed.proj.weight", &h->patch_w, {H, c->num_channels, c->patch_size, c->patch_size});
     rc |= add_param(h, p + "patch_embed.proj.bias", &h->patch_b, {H});
-    const int NP = (c->input_size / c->patch_size) * (c->input_size / c->patch_size);
     rc |= add_param(h, p + "cls_token", &h->cls_token, {1, 1, H});
     rc |= add_param(h, p + "pos_embed", &h->pos_embed, {1, NP + 1, H});
     rc |= add_param(h, p + "norm.weight", &h->norm_g, {H});
@@ -287,7 +344,6 @@ int ee_create(const ee_config* c, ee_handle** out) {
     rc |= add_param(h, p + "encoder.rel_pos_bias.weight", &h->rel1, {c->num_attention_heads, c->rel_pos_bins});
     rc |= add_param(h, p + "encoder.rel_pos_x_bias.weight", &h->relx, {c->num_attention_heads, c->rel_2d_pos_bins});
     rc |= add_param(h, p + "encoder.rel_pos_y_bias.weight", &h->rely, {c->num_attention_heads, c->rel_2d_pos_bins});
-    h->layers.resize(L);
     for (int l = 0; l < L && !rc; ++l) {
         LayerW& w = h->layers[l];
         const std::string q = p + "encoder.layer." + std::to_string(l) + ".";
@@ -310,18 +366,16 @@ int ee_create(const ee_config* c, ee_handle** out) {
         rc |= add_param(h, q + "output.LayerNorm.weight", &w.f_g, {H});
         rc |= add_param(h, q + "output.LayerNorm.bias", &w.f_beta, {H});
     }
-    const bool two = c->exit_head_num_layers == 2;
-    const int out_dim = c->strategy == MMEE_STRATEGY_RAMP ? K : 2;     // EE/models/LayoutLMv3.py:83
     const char* emb_nm[3] = {"vision_exit_embeddings", "text_exit_embeddings", "concat_exit_embeddings"};
     for (int i = 0; i < c->n_embedding_exits && !rc; ++i) {
         const int kind = c->embedding_exits[i];
         if (kind < 0 || kind > 2) { rc = fail(nullptr, "bad embedding exit kind"); break; }
         rc |= add_head(h, p + emb_nm[kind], &h->emb_heads[kind], H, out_dim, two);
     }
-    h->enc_heads.resize(c->n_encoder_exits);
     for (int k = 0; k < c->n_encoder_exits && !rc; ++k)
         rc |= add_head(h, p + "encoder.early_exits." + std::to_string(k), &h->enc_heads[k], H, out_dim, two);
     rc |= add_head(h, "classifier", &h->classifier, H, K, true);       // HF:799-823, always dense + out_proj
+    }
 
     // ---- workspace --------------------------------------------------------------------------------------------
     const size_t Bm = c->max_docs, Tm = c->max_text_len, Pv = NP + 1;
@@ -343,8 +397,8 @@ int ee_create(const ee_config* c, ee_handle** out) {
         rc |= dev_alloc(h, &h->hid2, Bm * H);
         rc |= dev_alloc(h, &h->head_logits, Bm * 64);
         rc |= dev_alloc(h, &h->pol_logits, Bm * 64);
-        rc |= dev_alloc(h, &h->text_dst, Bm * Tm);
-        rc |= dev_alloc(h, &h->emb_pos, Bm * Tm);
+        rc |= dev_alloc(h, &h->text_dst, Bm * Tm + 1);
+        rc |= dev_alloc(h, &h->emb_pos, Bm * Tm + 1);
         rc |= dev_alloc(h, &h->ntext, Bm);
         rc |= dev_alloc(h, &h->row_src, rows);
         rc |= dev_alloc(h, &h->err_flag, 4);
@@ -450,6 +504,21 @@ int ee_finalize(ee_handle* h) {
         }
     if (nmiss) return fail(h, "ee_finalize: %d parameter(s) not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? "..." : "");
     const ee_config& c = h->cfg;
+    if (c.arch == MMEE_ARCH_BEIT) {      // absolute position embeddings only: the attention kernel gets one-entry zero tables
+        h->c1 = h->c2 = 0;
+        h->n1 = h->n2 = 4;
+        if (!h->t1) {
+            if (dev_alloc(h, &h->t1, (size_t)c.num_attention_heads * 4)) return 1;
+            if (dev_alloc(h, &h->tx, (size_t)c.num_attention_heads * 4)) return 1;
+            if (dev_alloc(h, &h->ty, (size_t)c.num_attention_heads * 4)) return 1;
+        }
+        HIP_OK(h, hipMemset(h->t1, 0, sizeof(float) * c.num_attention_heads * 4));
+        HIP_OK(h, hipMemset(h->tx, 0, sizeof(float) * c.num_attention_heads * 4));
+        HIP_OK(h, hipMemset(h->ty, 0, sizeof(float) * c.num_attention_heads * 4));
+        HIP_OK(h, hipDeviceSynchronize());
+        h->finalized = true;
+        return 0;
+    }
     const int NP = (c.input_size / c.patch_size) * (c.input_size / c.patch_size);
     const int maxpos = std::max(c.max_text_len, NP + 1);
     h->c1 = maxpos - 1;
@@ -487,10 +556,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                float* out_hidden_cls, void* stream) {
     if (!h) return 1;
     if (!h->finalized) return fail(h, "ee_forward: call ee_finalize after loading the parameters");
-    if (!input_ids || !bbox || !pixel_values || !out_exit) return fail(h, "ee_forward: input_ids, bbox, pixel_values and out_exit are required");
     const ee_config& c = h->cfg;
+    const bool beit = c.arch == MMEE_ARCH_BEIT;
+    if (beit) T = 0;                                   // image-only: a document is its 197 visual rows
+    if (!pixel_values || !out_exit || (!beit && (!input_ids || !bbox)))
+        return fail(h, "ee_forward: pixel_values and out_exit (and input_ids, bbox for LayoutLMv3) are required");
     if (B < 1 || B > c.max_docs) return fail(h, "ee_forward: B=%d outside [1, max_docs=%d]", B, c.max_docs);
-    if (T < 1 || T > c.max_text_len) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
+    if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
     if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -519,6 +591,17 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     bool need[3] = {false, false, false};
     for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
 
+    if (beit) {
+        // ---- BEiT / DiT: uniform 197-row documents, BeitEmbeddings = patch conv + cls + absolute position embeddings ----
+        { ProfScope ps(h, P_PREP, s); launch_prep_uniform(B, Pv, S_doc_off(0), S_x_src(0), S_doc_orig(0), h->meta[0], h->counts, s); }
+        GemmArgs pg{};
+        pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
+        pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
+        pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
+        pg.tile_counter = next_head(); pg.prio_mode = 1;
+        { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
+        { ProfScope ps(h, P_EMBV, s); launch_embed_beit(h->vis_raw, h->cls_token, c.use_abs_pos ? h->pos_embed : nullptr, B, Pv, H, h->X, s); }
+    } else {
     // ---- stage 0: packed layout --------------------------------------------------------------------------------
     PrepArgs pa{};
     pa.input_ids = (const long long*)input_ids;
@@ -564,6 +647,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (need[MMEE_EXIT_VISION_AVG]) launch_pool_finish(h->vis_part, vch, H, (float)Pv, h->pooled[0], B, s);
         if (need[MMEE_EXIT_TEXT_AVG]) launch_pool_finish(h->text_part, tch, H, (float)T, h->pooled[1], B, s);
         if (need[MMEE_EXIT_TEXT_VISUAL_CONCAT]) launch_pool_finish(h->cat_part, tch + vch, H, (float)(T + Pv), h->pooled[2], B, s);
+    }
+
     }
 
     // ---- exit stages ---------------------------------------------------------------------------------------------
@@ -646,6 +731,32 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         const int* rows_ptr = &h->counts[cur].n_rows;
         const int* rs = use_row_src ? h->row_src : nullptr;
         h->layer_stage[l] = cur;
+        if (beit) {
+            // BeitLayer.forward (BEIT:406-444): pre-LN, layer scale.  Z = CTX buffer (LN output / attention output by turns)
+            GemmArgs g{};
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
+            g.A = h->CTX; g.lda = H; g.W = w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
+            g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
+            { ProfScope ps(h, P_GQKV, s); launch_gemm_f32(g, EPI_BIAS, AMODE_ROWS, max_rows, cus, s); }
+            AttnArgs at{};
+            at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
+            at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
+            at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
+            { ProfScope ps(h, P_ATTN, s); launch_attention_f32(at, B, cus, s); }
+            g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
+            g.A = h->CTX; g.lda = H; g.W = w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
+            g.col_scale = w.lam1; g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+            { ProfScope ps(h, P_GAO, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, h->CTX, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
+            g = GemmArgs{};
+            g.A = h->CTX; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f;
+            g.tile_counter = next_head(); g.prio_mode = 1;
+            { ProfScope ps(h, P_GUP, s); launch_gemm_f32(g, EPI_GELU, AMODE_ROWS, max_rows, cus, s); }
+            g = GemmArgs{};      // X = Y + lambda_2 * (h1 W2^T + b2)
+            g.A = h->H1; g.lda = I; g.W = w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H; g.col_scale = w.lam2;
+            g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+            { ProfScope ps(h, P_GDOWN, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
+        } else {
         GemmArgs g{};
         // QKV projection, Q pre-divided by sqrt(d) (HF:263)
         g.A = h->X; g.lda = H; g.row_src = rs; g.W = w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
@@ -661,7 +772,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         g.A = h->CTX; g.lda = H; g.W = w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
         g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GAO, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s); }
         // FFN (HF:485-512)
         g = GemmArgs{};
         g.A = h->Y; g.lda = H; g.W = w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
@@ -670,7 +781,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         g.A = h->H1; g.lda = I; g.W = w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
         g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GDOWN, s); launch_gemm_f32(g, EPI_RESID, AMODE_ROWS, max_rows, cus, s); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s); }
+        }
         // the layer wrote X densely in the numbering of stage `cur`
         x_phys = S_doc_off(cur);
         use_row_src = false;
@@ -682,7 +794,14 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             ++next_enc;
         }
     }
-    run_exit(nullptr, h->X, H, x_phys, true);
+    if (beit) {
+        // BeitPooler (BEIT:563-572): LayerNorm(mean of the patch tokens), then the Linear classifier
+        launch_patch_mean(h->X, H, x_phys, S_doc_off(cur), &h->counts[cur].n_docs, h->pooled[0], B, s);
+        launch_ln_rows(h->pooled[0], h->pooled[0], nullptr, &h->counts[cur].n_docs, B, H, h->ln_g, h->ln_b, c.layer_norm_eps, cus, s);
+        run_exit(nullptr, h->pooled[0], H, nullptr, true);
+    } else {
+        run_exit(nullptr, h->X, H, x_phys, true);
+    }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
     HIP_OK(h, hipGetLastError());
     return 0;

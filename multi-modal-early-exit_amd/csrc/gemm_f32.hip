@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs 
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
             const float sc = (col < g.scale_cols) ? g.scale : 1.0f;      // scale_cols is a multiple of 128
+            f32x4 lam = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs 
                             float x = (v[t] + bv[t]) * sc;
                             if (EPI == EPI_GELU) x = x * 0.5f * (1.0f + fast_erff(x * 0.70710678118654752440f));
                             if (EPI == EPI_TANH) x = tanhf(x);
-                            v[t] = x;
+                            v[t] = x * lam[t];
                         }
                         if (EPI == EPI_RESID) {
                             const int rs = g.resid_row_src ? g.resid_row_src[row] : row;

@@ -130,6 +130,7 @@ struct GemmArgs {
     int N, K;
     int scale_cols;              // columns [0, scale_cols) are multiplied by `scale` after the bias (Q / sqrt(d))
     float scale;
+    const float* col_scale;      // optional per-column factor applied to (acc + bias) before the residual (BEiT lambda_1/2)
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;

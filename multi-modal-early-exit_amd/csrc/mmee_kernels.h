@@ -94,11 +94,15 @@ void launch_preprocess_images(const unsigned char* images, const ImageDesc* desc
 void launch_collate_pad(const long long* ids, const long long* boxes, const long long* offsets, int B, int T, long long pad_id,
                         long long* out_ids, long long* out_mask, long long* out_bbox, hipStream_t s);
 void launch_prep(const PrepArgs& a, hipStream_t s);
+void launch_prep_uniform(int B, int Pv, int* doc_off, int* x_src, int* doc_orig, RowMeta* meta, StageCounts* counts, hipStream_t s);
 void launch_embed_text(const EmbedArgs& a, hipStream_t s);
 void launch_embed_visual(const EmbedArgs& a, hipStream_t s);
 void launch_pool_finish(const float* part, int chunks, int H, float count, float* pooled, int B, hipStream_t s);
-void launch_ln_rows(float* X, const int* n_rows_ptr, int max_rows, int H, const float* g, const float* b, float eps,
-                    int num_cus, hipStream_t s);
+void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
+                    const float* g, const float* b, float eps, int num_cus, hipStream_t s);
+void launch_embed_beit(const float* patch, const float* cls, const float* pos, int B, int Pv, int H, float* X, hipStream_t s);
+void launch_patch_mean(const float* X, int H, const int* x_phys, const int* doc_off, const int* n_docs_ptr, float* pooled,
+                       int max_docs, hipStream_t s);
 void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s);
 void launch_decide(const DecideArgs& a, hipStream_t s);
 void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,

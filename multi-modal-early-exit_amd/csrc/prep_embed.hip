@@ -311,23 +311,80 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
     }
 }
 
-// in-place row LayerNorm over the packed rows of the active stage
+// row LayerNorm over the packed rows of the active stage: dst[r] = LN(src[row_src ? row_src[r] : r]) (dst may be src)
 template <int NV>
-__global__ __launch_bounds__(256) void ln_rows_kernel(float* __restrict__ X, const int* __restrict__ n_rows_ptr, int H,
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                      const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
                                                       const float* __restrict__ g, const float* __restrict__ b, float eps) {
     const int n_rows = *n_rows_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
         f32x4 x[NV];
-        float* p = X + (size_t)r * H;
+        const float* p = src + (size_t)(row_src ? row_src[r] : r) * H;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
             x[i] = (c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
         }
         wave_layernorm<NV>(x, H, lane, g, b, eps);
-        wave_store_row<NV>(p, x, H, lane);
+        wave_store_row<NV>(dst + (size_t)r * H, x, H, lane);
     }
+}
+
+// BEiT / DiT embeddings (BeitEmbeddings.forward): X[b*Pv + v] = (v == 0 ? cls_token : patch[b][v-1]) + position_embeddings[v]
+__global__ __launch_bounds__(256) void embed_beit_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                         const float* __restrict__ pos, int B, int Pv, int H,
+                                                         float* __restrict__ X) {
+    const size_t total = (size_t)B * Pv * (H / 4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (H / 4));
+        const size_t row = i / (H / 4);
+        const int v = (int)(row % Pv);
+        const size_t bidx = row / Pv;
+        f32x4 e = (v == 0) ? *reinterpret_cast<const f32x4*>(cls + 4 * c4)
+                           : *reinterpret_cast<const f32x4*>(patch + (bidx * (Pv - 1) + (v - 1)) * H + 4 * c4);
+        if (pos) e += *reinterpret_cast<const f32x4*>(pos + (size_t)v * H + 4 * c4);
+        *reinterpret_cast<f32x4*>(X + row * H + 4 * c4) = e;
+    }
+}
+
+// BeitPooler with use_mean_pooling: pooled[i] = mean over rows 1..len-1 (patch tokens, CLS excluded) of active doc i
+__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ X, int H, const int* __restrict__ x_phys,
+                                                         const int* __restrict__ doc_off, const int* __restrict__ n_docs_ptr,
+                                                         float* __restrict__ pooled) {
+    const int n = *n_docs_ptr;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int len = doc_off[i + 1] - doc_off[i];
+        const float* base = X + (size_t)x_phys[i] * H;
+        for (int c = threadIdx.x; c < H; c += 256) {
+            float s = 0.f;
+            for (int r = 1; r < len; ++r) s += base[(size_t)r * H + c];
+            pooled[(size_t)i * H + c] = s / (float)(len - 1);
+        }
+    }
+}
+
+// image-only (BEiT / DiT) stage 0: every document is Pv rows, no relative-position metadata, every key valid
+__global__ __launch_bounds__(256) void prep_uniform_kernel(int B, int Pv, int* __restrict__ doc_off, int* __restrict__ x_src,
+                                                           int* __restrict__ doc_orig, RowMeta* __restrict__ meta,
+                                                           StageCounts* __restrict__ counts) {
+    const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int i = i0; i <= B; i += stride) {
+        doc_off[i] = i * Pv;
+        if (i < B) { x_src[i] = i * Pv; doc_orig[i] = i; }
+    }
+    for (int r = i0; r < B * Pv; r += stride) meta[r] = RowMeta{0, 0, 0, __float_as_int(0.0f)};
+    if (i0 == 0) {
+        counts->n_docs = B;
+        counts->n_rows = B * Pv;
+        counts->sum_len_sq = (unsigned long long)B * Pv * Pv;
+    }
+}
+
+void launch_prep_uniform(int B, int Pv, int* doc_off, int* x_src, int* doc_orig, RowMeta* meta, StageCounts* counts, hipStream_t s) {
+    int grid = (B * Pv + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(prep_uniform_kernel, dim3(grid), dim3(256), 0, s, B, Pv, doc_off, x_src, doc_orig, meta, counts);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -365,19 +422,32 @@ void launch_pool_finish(const float* part, int chunks, int H, float count, float
     hipLaunchKernelGGL(pool_finish_kernel, dim3(B), dim3(256), 0, s, part, chunks, H, count, pooled);
 }
 
-void launch_ln_rows(float* X, const int* n_rows_ptr, int max_rows, int H, const float* g, const float* b, float eps,
-                    int num_cus, hipStream_t s) {
+void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
+                    const float* g, const float* b, float eps, int num_cus, hipStream_t s) {
     int grid = (max_rows + 3) / 4;
     const int cap = num_cus * 8;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int nv = (H + 255) / 256;
     switch (nv) {
-        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
-        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
-        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
-        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, X, n_rows_ptr, H, g, b, eps); break;
+        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
+        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
+        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
+        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
     }
+}
+
+void launch_embed_beit(const float* patch, const float* cls, const float* pos, int B, int Pv, int H, float* X, hipStream_t s) {
+    size_t total = (size_t)B * Pv * (H / 4);
+    int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(embed_beit_kernel, dim3(grid), dim3(256), 0, s, patch, cls, pos, B, Pv, H, X);
+}
+
+void launch_patch_mean(const float* X, int H, const int* x_phys, const int* doc_off, const int* n_docs_ptr, float* pooled,
+                       int max_docs, hipStream_t s) {
+    int grid = max_docs < 4096 ? max_docs : 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(patch_mean_kernel, dim3(grid), dim3(256), 0, s, X, H, x_phys, doc_off, n_docs_ptr, pooled);
 }
 
 }  // namespace mmee

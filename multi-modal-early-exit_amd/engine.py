@@ -81,6 +81,13 @@ class EarlyExitEngine:
         c.criterion = ec.inference_strategy.code
         c.max_docs, c.max_text_len = self.max_docs, self.max_text_len
         c.precision = {"fp32": 0, "f32": 0, "bf16": 1}[precision]
+        self.beit = cfg.arch == "beit"
+        c.arch = 1 if self.beit else 0
+        c.use_abs_pos = int(cfg.use_absolute_position_embeddings)
+        c.layer_scale = int(cfg.layer_scale_init_value > 0)
+        c.use_mean_pooling = int(cfg.use_mean_pooling)
+        if self.beit:
+            c.max_text_len = self.max_text_len = 0
         self.precision = precision
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -162,26 +169,32 @@ class EarlyExitEngine:
             x = x.to(dtype)
         return x.contiguous()
 
-    def forward(self, input_ids, attention_mask=None, bbox=None, pixel_values=None, token_type_ids=None,
+    def forward(self, input_ids=None, attention_mask=None, bbox=None, pixel_values=None, token_type_ids=None,
                 position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
-        ids = self._dev(input_ids, torch.int64, "input_ids")
-        B, T = ids.shape
-        if bbox is None:
-            bbox = torch.zeros((B, T, 4), dtype=torch.int64, device=self.device)   # EE/models/LayoutLMv3.py:433-436
-        am = self._dev(attention_mask, torch.int64, "attention_mask", required=False)
-        bb = self._dev(bbox, torch.int64, "bbox")
-        px = self._dev(pixel_values, torch.float32, "pixel_values")
-        tt = self._dev(token_type_ids, torch.int64, "token_type_ids", required=False)
-        ps = self._dev(position_ids, torch.int64, "position_ids", required=False)
         R = self.cfg.input_size
-        if tuple(bb.shape) != (B, T, 4) or tuple(px.shape) != (B, self.cfg.num_channels, R, R):
-            raise ValueError(f"bbox must be (B,T,4) and pixel_values (B,{self.cfg.num_channels},{R},{R}); got "
-                             f"{tuple(bb.shape)} / {tuple(px.shape)}")
+        px = self._dev(pixel_values, torch.float32, "pixel_values")
+        if self.beit:                                   # image-only: (B,3,R,R) is the whole input
+            ids = am = bb = tt = ps = None
+            B, T = px.shape[0], 0
+            if tuple(px.shape) != (B, self.cfg.num_channels, R, R):
+                raise ValueError(f"pixel_values must be (B,{self.cfg.num_channels},{R},{R})")
+        else:
+            ids = self._dev(input_ids, torch.int64, "input_ids")
+            B, T = ids.shape
+            if bbox is None:
+                bbox = torch.zeros((B, T, 4), dtype=torch.int64, device=self.device)   # EE/models/LayoutLMv3.py:433-436
+            am = self._dev(attention_mask, torch.int64, "attention_mask", required=False)
+            bb = self._dev(bbox, torch.int64, "bbox")
+            tt = self._dev(token_type_ids, torch.int64, "token_type_ids", required=False)
+            ps = self._dev(position_ids, torch.int64, "position_ids", required=False)
+            if tuple(bb.shape) != (B, T, 4) or tuple(px.shape) != (B, self.cfg.num_channels, R, R):
+                raise ValueError(f"bbox must be (B,T,4) and pixel_values (B,{self.cfg.num_channels},{R},{R}); got "
+                                 f"{tuple(bb.shape)} / {tuple(px.shape)}")
         for t, n in ((am, "attention_mask"), (tt, "token_type_ids"), (ps, "position_ids")):
             if t is not None and tuple(t.shape) != (B, T):
                 raise ValueError(f"{n} must be (B,T)")

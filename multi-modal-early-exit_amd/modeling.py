@@ -158,6 +158,9 @@ class LayoutLMv3EEForSequenceClassification:
         out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                              token_type_ids=token_type_ids, position_ids=position_ids),
                         dump_all=True, want_all=True, want_head=True)
+        return self._pack(out, labels, return_dict)
+
+    def _pack(self, out: EngineOutput, labels, return_dict):
         E = self.engine.E
         logits = out.all_logits[E]
         exit_states = tuple((out.head_logits[j], out.head_crit[j]) for j in range(E))
@@ -185,6 +188,7 @@ class LayoutLMv3EEForSequenceClassification:
             return res.to_tuple()
         return res
 
+
     __call__ = forward
 
     # ---- the fast path ------------------------------------------------------------------------------------------------
@@ -199,3 +203,40 @@ class LayoutLMv3EEForSequenceClassification:
         return self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                               token_type_ids=token_type_ids, position_ids=position_ids),
                          thresholds=thresholds, temperatures=temperatures, **kw)
+
+
+class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
+    """Image-only DiT / BEiT classifier with per-layer exit heads on the same HIP kernels (BASELINE configs[4]).
+
+    The reference's "dit" branch loads a stock ``AutoModelForImageClassification`` (EE/configs.py:429-449) and defines no exit
+    heads for it; heads here are ``LayoutLMv3Exit`` (EE/models/LayoutLMv3.py:56-93) on the CLS row after each exit layer
+    (``beit.encoder.early_exits.k``) — a documented extrapolation.  ``forward(pixel_values, labels=None)`` returns
+    the same ``EESequenceClassifierOutput`` fields; ``early_exit(pixel_values=...)`` is the fast path."""
+
+    def forward(self, pixel_values=None, labels=None, head_mask=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, **kwargs) -> EESequenceClassifierOutput:
+        if pixel_values is None:
+            raise ValueError("pixel_values is required")
+        if head_mask is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("head_mask / attention maps / full hidden states are not part of the evaluation hot path")
+        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True)
+        return self._pack(out, labels, return_dict)
+
+    __call__ = forward
+
+    def _run(self, tensors, **kw):
+        px = tensors["pixel_values"]
+        B, mb = px.shape[0], self.engine.max_docs
+        if B <= mb:
+            return self.engine.forward(pixel_values=px, **kw)
+        parts = [self.engine.forward(pixel_values=px[s:s + mb], **kw) for s in range(0, B, mb)]
+        cat = lambda xs, d: None if xs[0] is None else torch.cat(xs, dim=d)
+        return EngineOutput(cat([p.logits for p in parts], 0), cat([p.exit_layer for p in parts], 0),
+                            cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
+                            cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
+                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1))
+
+    def early_exit(self, pixel_values=None, thresholds=None, temperatures=None, **kw) -> EngineOutput:
+        if thresholds is None:
+            thresholds = self.config.exit_config["global_threshold"]
+        return self._run(dict(pixel_values=pixel_values), thresholds=thresholds, temperatures=temperatures, **kw)

@@ -98,6 +98,52 @@ def make_weights(cfg: ModelConfig, seed: int = 1234, head_gain: float = 30.0, ln
     return w
 
 
+def make_weights_beit(cfg: ModelConfig, seed: int = 1234, head_gain: float = 30.0, ln_jitter: float = 0.1) -> Dict[str, np.ndarray]:
+    """Random-init BEiT / DiT parameters under the transformers-4.x names of the DiT checkpoints (``beit.encoder.layer.N.
+    attention.attention.query`` ...), plus this build's per-layer exit heads ``beit.encoder.early_exits.k``."""
+    rng = np.random.default_rng(seed)
+    H, I, K = cfg.hidden_size, cfg.intermediate_size, cfg.num_labels
+    ec = cfg.exit_config
+    w: Dict[str, np.ndarray] = {}
+
+    def lin(name, out_f, in_f, gain=1.0, bias=True):
+        w[f"{name}.weight"] = _normal(rng, (out_f, in_f)) * np.float32(gain)
+        if bias:
+            w[f"{name}.bias"] = _normal(rng, (out_f,)) * np.float32(gain)
+
+    def ln(name):
+        w[f"{name}.weight"] = (1.0 + ln_jitter * rng.standard_normal(H, dtype=np.float32)).astype(np.float32)
+        w[f"{name}.bias"] = (ln_jitter * rng.standard_normal(H, dtype=np.float32)).astype(np.float32)
+
+    p = "beit."
+    w[p + "embeddings.cls_token"] = _normal(rng, (1, 1, H))
+    if cfg.use_absolute_position_embeddings:
+        w[p + "embeddings.position_embeddings"] = _normal(rng, (1, cfg.visual_len, H))
+    w[p + "embeddings.patch_embeddings.projection.weight"] = _normal(rng, (H, cfg.num_channels, cfg.patch_size, cfg.patch_size))
+    w[p + "embeddings.patch_embeddings.projection.bias"] = _normal(rng, (H,))
+    for l in range(cfg.num_hidden_layers):
+        q = f"{p}encoder.layer.{l}."
+        lin(q + "attention.attention.query", H, H, gain=2.5)
+        lin(q + "attention.attention.key", H, H, gain=2.5, bias=False)        # BeitSelfAttention.key has no bias
+        lin(q + "attention.attention.value", H, H)
+        lin(q + "attention.output.dense", H, H)
+        lin(q + "intermediate.dense", I, H)
+        lin(q + "output.dense", H, I)
+        ln(q + "layernorm_before")
+        ln(q + "layernorm_after")
+        if cfg.layer_scale_init_value > 0:
+            w[q + "lambda_1"] = (cfg.layer_scale_init_value * (1.0 + 0.3 * rng.standard_normal(H, dtype=np.float32))).astype(np.float32)
+            w[q + "lambda_2"] = (cfg.layer_scale_init_value * (1.0 + 0.3 * rng.standard_normal(H, dtype=np.float32))).astype(np.float32)
+    ln(p + "pooler.layernorm")
+    out_dim = K if str(ec.encoder_layer_strategy) == "ramp" else 2
+    for k, _ in enumerate(ec.encoder_exit_layers):
+        if ec.exit_head_num_layers == 2:
+            lin(f"{p}encoder.early_exits.{k}.dense", H, H, gain=2.0)
+        lin(f"{p}encoder.early_exits.{k}.out_proj", out_dim, H, gain=head_gain)
+    lin("classifier", K, H, gain=head_gain)
+    return w
+
+
 def make_documents(cfg: ModelConfig, n_docs: int, seed: int = 1234, text_len: int = 512,
                    min_words: int = 16, max_words: Optional[int] = None, labels: bool = True) -> Dict[str, np.ndarray]:
     """RVL-CDIP-shaped synthetic batch (distributions of SURVEY.md section 8d)."""

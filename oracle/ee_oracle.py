@@ -502,3 +502,75 @@ def preprocess_image(img: np.ndarray, size: int = 224) -> np.ndarray:
     """(H,W,3) uint8 RGB -> (3,size,size) float32 pixel_values."""
     r = pil_bilinear_resize_u8(img, size, size)
     return rescale_normalize_lut()[r].transpose(2, 0, 1).copy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: image-only DiT (BEiT architecture) with per-layer exit heads
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's "dit" branch loads a stock AutoModelForImageClassification (EE/configs.py:429-449) and has NO exit
+# heads for it (SURVEY.md section 8d calls config 5 an extrapolation).  The encoder below restates HF BEiT
+# (``BEIT:N`` = transformers/models/beit/modeling_beit.py at 5.15.0; parameter names are the 4.x ones of the DiT
+# checkpoints); exit k = LayoutLMv3Exit (EE/models/LayoutLMv3.py:86-93) on the CLS row after encoder layer k.
+def forward_all_beit(cfg, W: Dict[str, np.ndarray], pixel_values: np.ndarray, exits: Sequence[int], strategy: str = "ramp",
+                     criterion: str = "max_confidence", return_hidden_cls: bool = False) -> Dict[str, np.ndarray]:
+    p = "beit."
+    B, C, R, _ = pixel_values.shape
+    P, g = cfg.patch_size, cfg.input_size // cfg.patch_size
+    H = cfg.hidden_size
+    nh, d = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    x = pixel_values.astype(F32).reshape(B, C, g, P, g, P).transpose(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P)
+    x = linear(x, W[p + "embeddings.patch_embeddings.projection.weight"].reshape(H, C * P * P),
+               W[p + "embeddings.patch_embeddings.projection.bias"])                                   # BEIT:63-90
+    x = np.concatenate([np.broadcast_to(W[p + "embeddings.cls_token"].reshape(1, 1, H), (B, 1, H)), x], axis=1)
+    if p + "embeddings.position_embeddings" in W:
+        x = x + W[p + "embeddings.position_embeddings"].reshape(1, -1, H)                             # BEIT:168-172
+    x = x.astype(F32)
+    enc_exits = sorted(int(e) for e in exits)
+    crit_fn = max_confidence if criterion == "max_confidence" else entropy
+    ex_logits, gate_inputs, cls_rows = [], [], [x[:, 0, :].copy()]
+    k = 0
+    for l in range(cfg.num_hidden_layers):                                                            # BEIT:406-444
+        q = f"{p}encoder.layer.{l}."
+        hN = layer_norm(x, W[q + "layernorm_before.weight"], W[q + "layernorm_before.bias"], cfg.layer_norm_eps)
+        def heads(t):
+            return t.reshape(B, -1, nh, d).transpose(0, 2, 1, 3)
+        Q = heads(linear(hN, W[q + "attention.attention.query.weight"], W[q + "attention.attention.query.bias"]))
+        K = heads(linear(hN, W[q + "attention.attention.key.weight"], None))                          # no key bias, BEIT:306
+        V = heads(linear(hN, W[q + "attention.attention.value.weight"], W[q + "attention.attention.value.bias"]))
+        s = (Q @ K.transpose(0, 1, 3, 2)) * F32(d ** -0.5)                                            # BEIT:281-284
+        s = s - s.max(axis=-1, keepdims=True)
+        es = np.exp(s, dtype=F32)
+        pr = (es / es.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        ctx = (pr @ V).transpose(0, 2, 1, 3).reshape(B, -1, H)
+        a = linear(ctx, W[q + "attention.output.dense.weight"], W[q + "attention.output.dense.bias"])
+        if q + "lambda_1" in W:
+            a = W[q + "lambda_1"] * a
+        x = (a + x).astype(F32)
+        hN = layer_norm(x, W[q + "layernorm_after.weight"], W[q + "layernorm_after.bias"], cfg.layer_norm_eps)
+        f = gelu(linear(hN, W[q + "intermediate.dense.weight"], W[q + "intermediate.dense.bias"]))
+        f = linear(f, W[q + "output.dense.weight"], W[q + "output.dense.bias"])
+        if q + "lambda_2" in W:
+            f = W[q + "lambda_2"] * f
+        x = (f + x).astype(F32)
+        cls_rows.append(x[:, 0, :].copy())
+        if (l + 1) in enc_exits:
+            xin = x[:, 0, :]
+            ex_logits.append(exit_head(xin, W, f"{p}encoder.early_exits.{k}")); gate_inputs.append(xin.copy())
+            k += 1
+    pooled = layer_norm(x[:, 1:, :].mean(axis=1, dtype=F32), W[p + "pooler.layernorm.weight"], W[p + "pooler.layernorm.bias"],
+                        cfg.layer_norm_eps)                                                           # BEIT:563-572
+    logits = linear(pooled, W["classifier.weight"], W["classifier.bias"])
+    E, Kc = len(ex_logits), logits.shape[1]
+    out: Dict[str, np.ndarray] = {"logits": logits, "final_crit": crit_fn(logits)}
+    out["exit_logits"] = np.stack(ex_logits) if E else np.zeros((0, B, Kc), F32)
+    out["exit_crit"] = np.stack([crit_fn(z) for z in ex_logits]) if E else np.zeros((0, B), F32)
+    store = np.zeros((E + 1, B, Kc), dtype=np.float64)
+    for j in range(E):
+        store[j] = ex_logits[j] if strategy != "gate" else linear(
+            layer_norm(gate_inputs[j], W[p + "pooler.layernorm.weight"], W[p + "pooler.layernorm.bias"], cfg.layer_norm_eps),
+            W["classifier.weight"], W["classifier.bias"])
+    store[-1] = logits
+    out["logits_store"] = store
+    if return_hidden_cls:
+        out["hidden_cls"] = np.stack(cls_rows)
+    return out

@@ -38,3 +38,5 @@ TINY_CASES = {
                                      exit_head_num_layers=1),
 }
 BASE_EE = dict(exits=["text_visual_concat", 2, 4, 6, 8, 10], encoder_layer_strategy="ramp")
+DIT_EE = dict(exits=[1, 2, 3, 4], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+DIT_BASE_EE = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp", inference_strategy="max_confidence")

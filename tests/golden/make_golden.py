@@ -217,9 +217,78 @@ def make_preprocess_golden():
     print("preprocess golden done")
 
 
+DIT_EE = dict(exits=[1, 2, 3, 4], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+DIT_BASE_EE = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+
+
+def make_dit_golden():
+    """BASELINE configs[4]: stock HF BeitForImageClassification (what the reference's "dit" branch loads) + the reference's
+    LayoutLMv3Exit heads on the CLS row after each exit layer (this build's extrapolation — the reference has no DiT exits)."""
+    from transformers import BeitConfig, BeitForImageClassification
+
+    def run(cfg, ee, seed_w, n_docs, seed_docs):
+        W = pkg.synth.make_weights_beit(cfg, seed=seed_w)
+        bc = BeitConfig(hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                        num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                        image_size=cfg.input_size, patch_size=cfg.patch_size, num_labels=cfg.num_labels,
+                        layer_norm_eps=cfg.layer_norm_eps, use_absolute_position_embeddings=True, use_relative_position_bias=False,
+                        use_shared_relative_position_bias=False, use_mean_pooling=True,
+                        layer_scale_init_value=cfg.layer_scale_init_value, use_mask_token=False, hidden_dropout_prob=0.0,
+                        attention_probs_dropout_prob=0.0, drop_path_rate=0.0)
+        m = BeitForImageClassification(bc).eval()
+        ren = {"attention.attention.query": "attention.q_proj", "attention.attention.key": "attention.k_proj",
+               "attention.attention.value": "attention.v_proj", "attention.output.dense": "attention.o_proj",
+               "intermediate.dense": "mlp.fc1", "output.dense": "mlp.fc2"}
+        sd = {}
+        for k, v in W.items():
+            if "early_exits" in k:
+                continue
+            k2 = k.replace("beit.encoder.layer.", "beit.layers.")
+            for a, b in ren.items():
+                k2 = k2.replace(a, b)
+            sd[k2] = torch.from_numpy(v)
+        missing, unexpected = m.load_state_dict(sd, strict=False)
+        assert not unexpected and all("mask_token" in x for x in missing), (missing, unexpected)
+        bc.exit_config = RefExitConfig(**ee).__dict__
+        bc.classifier_dropout = None
+        heads = []
+        for k in range(len(ee["exits"])):
+            n = f"beit.encoder.early_exits.{k}"
+            hd = RefExit(bc, cfg.hidden_size, n).eval()
+            hd.load_state_dict({kk[len(n) + 1:]: torch.from_numpy(v) for kk, v in W.items() if kk.startswith(n + ".")})
+            heads.append(hd)
+        pix = pkg.synth.make_documents(cfg, n_docs, seed=seed_docs, text_len=8)["pixel_values"]
+        layer_out = []
+        hooks = [l.register_forward_hook(lambda mod, i, o: layer_out.append(o if torch.is_tensor(o) else o[0])) for l in m.beit.layers]
+        emb = []
+        h0 = m.beit.layers[0].register_forward_pre_hook(lambda mod, a: emb.append(a[0]))
+        out = m(pixel_values=torch.from_numpy(pix))
+        [h.remove() for h in hooks]; h0.remove()
+        ex = [heads[k](layer_out[l - 1][:, 0, :]) for k, l in enumerate(sorted(ee["exits"]))]
+        store = np.zeros((len(ex) + 1,) + tuple(out.logits.shape), np.float64)
+        store[:-1] = torch.stack(ex).numpy()
+        store[-1] = out.logits.numpy()
+        return {"seed_w": seed_w, "seed_docs": seed_docs, "n_docs": n_docs,
+                "hidden_cls": torch.stack([emb[0][:, 0, :]] + [o[:, 0, :] for o in layer_out]).numpy(),
+                "exit_logits": torch.stack(ex).numpy(), "exit_crit": torch.stack([ref_maxconf(z) for z in ex]).numpy(),
+                "logits": out.logits.numpy(), "logits_store": store}
+
+    cfg = pkg.ModelConfig.dit_tiny(EE_config=DIT_EE)
+    res = run(cfg, DIT_EE, 5, 6, 6)
+    policy_fixture(res["logits_store"], [0.0, 0.5, 0.9, 1.0 + 1e-6], "pol", res)
+    np.savez_compressed(os.path.join(HERE, "dit_tiny.npz"), **res)
+    cfg = pkg.ModelConfig.dit_base(EE_config=DIT_BASE_EE)
+    res = run(cfg, DIT_BASE_EE, 1234, 3, 77)
+    np.savez_compressed(os.path.join(HERE, "dit_base_cls.npz"), **res)
+    print("dit golden done", res["logits"][0, :4])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         make_preprocess_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dit":
+        make_dit_golden()
     else:
         main()
         make_preprocess_golden()
+        make_dit_golden()

@@ -253,3 +253,17 @@ def test_device_collation_and_feeder(pkg):
         assert batch["labels"].tolist() == [s["labels"] for s in samples[seen:seen + b]]
         seen += b
     assert seen == 7
+
+
+def test_dit_model_wrapper(pkg):
+    from .conftest import DIT_EE
+    import torch
+    g = load_golden("dit_tiny")
+    cfg = pkg.ModelConfig.dit_tiny(EE_config=DIT_EE)
+    m = pkg.DiTEEForImageClassification(cfg, pkg.synth.make_weights_beit(cfg, seed=int(g["seed_w"])), max_docs=4)
+    pix = torch.from_numpy(pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=8)["pixel_values"])
+    out = m(pixel_values=pix, labels=torch.zeros(pix.shape[0], dtype=torch.int64))           # 6 docs through a 4-doc engine
+    np.testing.assert_allclose(out.logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+    assert len(out.exit_states) == 4 and len(out.exit_criteria) == 5 and out.loss is not None
+    ee = m.early_exit(pixel_values=pix, thresholds=float(g["pol_thr1"]))
+    assert np.array_equal(ee.exit_layer.cpu().numpy(), g["pol_exits1"])

@@ -121,3 +121,25 @@ def test_base_shape_matches_golden(pkg):
                           thresholds=float(g[f"pol_thr{i}"]))
         assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"])
     eng.close()
+
+
+def test_dit_image_only_variant_matches_golden(pkg, oracle):
+    """BASELINE configs[4]: image-only DiT/BEiT through the same GEMM / attention / exit-compaction kernels."""
+    from .conftest import DIT_BASE_EE, DIT_EE
+    for name, mk, ee in (("dit_tiny", pkg.ModelConfig.dit_tiny, DIT_EE), ("dit_base_cls", pkg.ModelConfig.dit_base, DIT_BASE_EE)):
+        g = load_golden(name)
+        cfg = mk(EE_config=ee)
+        W = pkg.synth.make_weights_beit(cfg, seed=int(g["seed_w"]))
+        pix = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=8)["pixel_values"]
+        eng = pkg.EarlyExitEngine(cfg, max_docs=8)
+        eng.load_weights(W)
+        out = eng.forward(pixel_values=pix, dump_all=True, want_all=True, want_head=True, want_hidden_cls=True, validate=True)
+        np.testing.assert_allclose(_np(out.hidden_cls), g["hidden_cls"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(_np(out.head_logits), g["exit_logits"], rtol=0, atol=LOGIT_TOL)
+        np.testing.assert_allclose(_np(out.all_logits), g["logits_store"], rtol=0, atol=LOGIT_TOL)
+        if name == "dit_tiny":
+            for i in range(4):
+                o2 = eng.forward(pixel_values=pix, thresholds=float(g[f"pol_thr{i}"]))
+                assert np.array_equal(_np(o2.exit_layer), g[f"pol_exits{i}"])
+                np.testing.assert_allclose(_np(o2.logits), g[f"pol_pred{i}"], rtol=0, atol=LOGIT_TOL)
+        eng.close()

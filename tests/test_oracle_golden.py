@@ -99,3 +99,17 @@ def test_torch_oracle_matches_numpy_oracle(pkg, oracle):
         docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
         out = ot.TorchOracle(cfg, W).forward_all(docs, ee["exits"], strategy=ee["encoder_layer_strategy"])
         np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+
+
+def test_dit_oracle_matches_hf_beit_golden(pkg, oracle):
+    """BASELINE configs[4]: the BEiT restatement against stock HF BeitForImageClassification + the reference's exit-head class."""
+    from .conftest import DIT_BASE_EE, DIT_EE
+    for name, mk, ee, tol in (("dit_tiny", pkg.ModelConfig.dit_tiny, DIT_EE, 2e-5), ("dit_base_cls", pkg.ModelConfig.dit_base, DIT_BASE_EE, 5e-5)):
+        g = load_golden(name)
+        cfg = mk(EE_config=ee)
+        W = pkg.synth.make_weights_beit(cfg, seed=int(g["seed_w"]))
+        pix = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=8)["pixel_values"]
+        out = oracle.forward_all_beit(cfg, W, pix, ee["exits"], return_hidden_cls=True)
+        np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], rtol=0, atol=tol)
+        np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out["exit_crit"], g["exit_crit"], rtol=0, atol=1e-5)
