@@ -121,11 +121,40 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    dev = torch.device(f"cuda:{local}")
+    # one process per GPU over RCCL ("nccl"); MMEE_DIST_BACKEND=gloo lets two ranks share one GPU to rehearse the flow on a
+    # one-GPU box (collectives then travel through host memory)
+    backend = os.environ.get("MMEE_DIST_BACKEND", "nccl")
+    ndev = max(1, torch.cuda.device_count())
+    local_dev = local % ndev if backend != "nccl" else local
+    dev = torch.device(f"cuda:{local_dev}")
     torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
+
+    def bcast(t):
+        x = t.to(cdev)
+        dist.broadcast(x, 0)
+        return x.to(t.device)
+
+    def allgather_rows(t):
+        x = t.to(cdev).contiguous()
+        outs = [torch.empty_like(x) for _ in range(world)] if backend != "nccl" else None
+        if backend == "nccl":
+            g = torch.empty((world * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(g, x)
+            return g
+        dist.all_gather(outs, x)
+        return torch.cat(outs, 0).to(t.device)
+
+    def allmax(v):
+        x = torch.tensor([v], dtype=torch.float64, device=cdev)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        return float(x.item())
+
     pkg = importlib.import_module("multi-modal-early-exit_amd")
 
     global EXIT_LAYERS
@@ -164,9 +193,7 @@ def main():
         conf = out.all_crit.cpu().numpy().astype(np.float64)
         thr = calibrate_thresholds(conf, a.release)
     if world > 1:                       # every rank uses rank 0's thresholds
-        t = torch.from_numpy(thr).to(dev)
-        dist.broadcast(t, 0)
-        thr = t.cpu().numpy()
+        thr = bcast(torch.from_numpy(thr).to(dev)).cpu().numpy()
 
     def step():
         return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows, temperatures=temps)
@@ -184,8 +211,7 @@ def main():
         results.append(torch.cat([out.logits, out.exit_layer.float().unsqueeze(1), out.confidence.unsqueeze(1)], dim=1))
     local_res = torch.cat(results, dim=0)
     if world > 1:                       # the one collective of the path: per-document (logits, exit, confidence)
-        gathered = torch.empty((world * local_res.shape[0], local_res.shape[1]), dtype=local_res.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, local_res)
+        gathered = allgather_rows(local_res)
     else:
         gathered = local_res
     torch.cuda.synchronize()
@@ -194,9 +220,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = allmax(dt)
 
     n_docs = gathered.shape[0]
     exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
