@@ -402,7 +402,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
         rc |= dev_alloc(h, &h->ntext, Bm);
         rc |= dev_alloc(h, &h->row_src, rows);
         rc |= dev_alloc(h, &h->err_flag, 4);
-        h->n_queue_heads = 8 * L + 4 * (E + 1) + 16;
+        h->n_queue_heads = 128 * (8 * L + 4 * (E + 1) + 16);     // 8 XCD-local heads per launch, one 64-byte line each
         rc |= dev_alloc(h, &h->queue_heads, (size_t)h->n_queue_heads);
         rc |= dev_alloc(h, &h->meta[0], rows);
         rc |= dev_alloc(h, &h->meta[1], rows);
@@ -584,8 +584,11 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
     h->next_queue_head = 0;
-    auto next_head = [&]() -> int* {
-        return h->next_queue_head < h->n_queue_heads ? h->queue_heads + h->next_queue_head++ : nullptr;
+    auto next_head = [&]() -> int* {                      // 8 XCD-local counters x 16 ints (one 64-byte line each)
+        if (h->next_queue_head + 128 > h->n_queue_heads) return nullptr;
+        int* p = h->queue_heads + h->next_queue_head;
+        h->next_queue_head += 128;
+        return p;
     };
     if (h->prof_on) { h->prof_recs.clear(); h->prof_used = 0; }
     bool need[3] = {false, false, false};
@@ -959,8 +962,8 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
     g.scale = 1.f;
     g.clk_probe = (unsigned long long*)clk_probe;
     static int* dbg_head = nullptr;
-    if (!dbg_head && hipMalloc((void**)&dbg_head, 64) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
-    if (hipMemsetAsync(dbg_head, 0, 64, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
+    if (!dbg_head && hipMalloc((void**)&dbg_head, 512) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
+    if (hipMemsetAsync(dbg_head, 0, 512, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
     g.tile_counter = (epi & 16) ? nullptr : dbg_head;    // epi | 16 = static grid stride (A/B switch)
     g.dbg_noload = (epi & 32) ? 1 : 0;
     g.prio_mode = (epi >> 6) & 3;                         // epi | 64 / 128: static priority variants                    // epi | 32 = no in-loop global loads (timing diagnostic)

@@ -78,19 +78,48 @@ __global__ __launch_bounds__(256, GEMM_WGS) void gemm_f32_kernel(const GemmArgs 
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
     unsigned long long acc_issue = 0, acc_comp = 0, acc_store = 0, acc_bar = 0, acc_pro = 0, acc_epi = 0;
     if (g.clk_probe) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    // Tiles are handed out by an atomic work-queue counter (zeroed by the host before the launch) instead of a static
-    // grid stride: workgroups run at slightly different speeds (cache / fabric position), and with ~87 tiles each the
-    // static split left the average workgroup idle for 6.7 % of the kernel waiting for the slowest one.
+    // Tiles are handed out by atomic work queues (zeroed by the host before the launch) instead of a static grid stride:
+    // workgroups run at slightly different speeds, and with ~87 tiles each a static split left the average workgroup
+    // idle for 6.7 % of the kernel waiting for the slowest one.
+    // The queues are XCD-local (each XCD has its own 4 MB L2): m-panels are dealt to the 8 XCDs in groups of GM = 8, and
+    // inside a queue the order is group -> n -> m, so the 64 workgroups of an XCD work on 8 A panels x 8 W panels at a
+    // time and walk along n with the A panels staying in L2 — instead of every A panel being fetched by every XCD
+    // (measured 9.4 GB fetched per FFN-up launch against 0.5 GB of A).  A workgroup whose queue is empty steals from the
+    // next XCD's queue, so placement only affects speed, never coverage: every tile index of every queue is popped once.
+    constexpr int GM = 8;
     int* q_slot = reinterpret_cast<int*>(smem + MAIN_LDS_FLOATS);
+    const int n_groups = (tiles_m + GM - 1) / GM;
+    const int my_xcd = g.tile_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
+    int q_try = 0;                                  // queues tried since the last successful pop (uniform over the WG)
     int tile = blockIdx.x;
     for (;; tile += gridDim.x) {
+        int tm, tn;
         if (g.tile_counter) {
-            if (tid == 0) *q_slot = atomicAdd(g.tile_counter, 1);
-            __syncthreads();
-            tile = *q_slot;
+            bool got = false;
+            while (q_try < 8) {
+                const int q = (my_xcd + q_try) & 7;
+                if (tid == 0) *q_slot = atomicAdd(g.tile_counter + 16 * q, 1);     // one counter per 64-byte line
+                __syncthreads();
+                const int j = *q_slot;
+                __syncthreads();
+                // queue q owns groups q, q+8, q+16, ...; each group is GM m-panels x tiles_n n-tiles (m fastest)
+                const int per_group = GM * tiles_n;
+                const int gl = j / per_group, r = j - gl * per_group;
+                const int grp = q + 8 * gl;
+                if (grp < n_groups) {
+                    tn = r / GM;
+                    tm = grp * GM + (r - tn * GM);
+                    if (tm < tiles_m) { got = true; break; }
+                    continue;                       // padding slot of the last (partial) group: pop again
+                }
+                ++q_try;                            // this queue is exhausted for good: move on to the next XCD's
+            }
+            if (!got) break;
+        } else {
+            if (tile >= n_tiles) break;
+            tm = tile / tiles_n;
+            tn = tile - tm * tiles_n;
         }
-        if (tile >= n_tiles) break;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- per-thread source pointers of the 4 A rows and 4 W rows this thread stages -------------------------
