@@ -60,20 +60,45 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
     const int n_items = n_docs * a.heads * qtiles;
     int cur_head = -1;
 
-    // work items (document, head, 128-query tile) differ a lot in cost (ragged lengths): hand them out dynamically
+    // Work items (document, head, 128-query tile) differ a lot in cost (ragged lengths), so they are handed out by atomic
+    // work queues.  The queues are XCD-local: (document, head) pair p belongs to queue p % 8 and its query tiles are
+    // consecutive in that queue, so the K/V rows of a pair (236 KB at 462 rows) are fetched into ONE XCD's L2 and re-used
+    // by the pair's 4-6 query tiles instead of being pulled over the fabric by up to 6 different XCDs.  A workgroup whose
+    // queue is empty steals from the next XCD's queue (placement affects speed only; every index is popped exactly once).
     int* q_slot = reinterpret_cast<int*>(TY + a.n2);
+    const int n_pairs = n_docs * a.heads;
+    const int my_xcd = a.item_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
+    int q_try = 0;
     int item = blockIdx.x;
     for (;; item += gridDim.x) {
+        int doc, head, qt;
         if (a.item_counter) {
-            __syncthreads();                           // everyone has read the previous slot value
-            if (tid == 0) *q_slot = atomicAdd(a.item_counter, 1);
-            __syncthreads();
-            item = *q_slot;
+            bool got = false;
+            while (q_try < 8) {
+                const int q = (my_xcd + q_try) & 7;
+                __syncthreads();                       // everyone has read the previous slot value
+                if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
+                __syncthreads();
+                const int j = *q_slot;
+                const int pl = j / qtiles;             // local pair index inside queue q
+                const int pair = q + 8 * pl;
+                if (pair < n_pairs) {
+                    qt = j - pl * qtiles;
+                    doc = pair / a.heads;
+                    head = pair - doc * a.heads;
+                    got = true;
+                    break;
+                }
+                ++q_try;
+            }
+            if (!got) break;
+        } else {
+            if (item >= n_items) break;
+            doc = item / (a.heads * qtiles);
+            const int rem = item - doc * (a.heads * qtiles);
+            head = rem / qtiles;
+            qt = rem - head * qtiles;
         }
-        if (item >= n_items) break;
-        const int doc = item / (a.heads * qtiles);
-        const int rem = item - doc * (a.heads * qtiles);
-        const int head = rem / qtiles, qt = rem - head * qtiles;
         const int off = a.doc_off[doc];
         const int len = a.doc_off[doc + 1] - off;
         const int q0 = qt * QT;
