@@ -965,8 +965,9 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
     if (!dbg_head && hipMalloc((void**)&dbg_head, 512) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
     if (hipMemsetAsync(dbg_head, 0, 512, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
     g.tile_counter = (epi & 16) ? nullptr : dbg_head;    // epi | 16 = static grid stride (A/B switch)
-    g.dbg_noload = (epi & 32) ? 1 : 0;
-    g.prio_mode = (epi >> 6) & 3;                         // epi | 64 / 128: static priority variants                    // epi | 32 = no in-loop global loads (timing diagnostic)
+    g.dbg_noload = ((epi & 32) ? 1 : 0) | ((epi & 512) ? 2 : 0) | ((epi & 1024) ? 4 : 0) | (((epi >> 12) & 255) << 8);   // epi bits 12..19: stagger (x 8128 cycles) for odd wave slots   // epi | 512 = no k-loop barrier (DMA variant; timing diagnostic, wrong results)
+    g.prio_mode = (epi >> 6) & 3;                         // epi | 64 / 128: static priority variants
+    g.use_dma = ((epi >> 8) & 1) ? 1 : 2;                 // epi | 256: LDS-DMA staging kernel, else the register-staged one                    // epi | 32 = no in-loop global loads (timing diagnostic)
     epi &= 15;
     g.row_src = row_src;
     g.resid_row_src = row_src;

@@ -134,6 +134,7 @@ struct GemmArgs {
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;
+    int use_dma;                     // 0 = default (LDS-DMA kernel unless MMEE_GEMM_DMA=0), 1 = LDS-DMA kernel, 2 = register-staged kernel
     int prio_mode;                   // 0 none, 1 raise the priority of odd hardware wave slots, 2 of the second half of the grid
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
     int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride

@@ -48,7 +48,7 @@ def run(M, N, K, epi=0, wgs=2, iters=10, check=False, fold=0):
         print(f"   per-WG alive time (us): first half mean {t[:len(t)//2].mean():.0f}  second half mean {t[len(t)//2:].mean():.0f}  "
               f"min {t.min():.0f} max {t.max():.0f}; by (wg>>3)&63 parity: {t[(np.arange(len(t))>>3)%2==0].mean():.0f} / {t[(np.arange(len(t))>>3)%2==1].mean():.0f}")
     print(f"M={M} N={N} K={K} epi={epi} fold={fold} wgs/cu={wgs}: {ms:.3f} ms  {tf:.1f} TFLOP/s ({tf / 157.3:.1%})  clock {ghz:.2f} GHz -> "
-          f"{tf / (157.3 * ghz / 2.4):.1%} of the peak at that clock", flush=True)
+          f"{(tf / (157.3 * ghz / 2.4)) if ghz else 0.0:.1%} of the peak at that clock", flush=True)
     return tf
 
 
