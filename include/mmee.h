@@ -47,7 +47,12 @@ enum { MMEE_CRIT_MAX_CONFIDENCE = 0, MMEE_CRIT_ENTROPY = 1 };
  * the reference's "dit" branch EE/configs.py:429-449 — exit heads there are this build's extrapolation) */
 enum { MMEE_ARCH_LAYOUTLMV3 = 0, MMEE_ARCH_BEIT = 1 };
 /* arithmetic of the encoder GEMMs */
-enum { MMEE_PREC_F32 = 0, MMEE_PREC_BF16 = 1 };
+/* MMEE_PREC_F32: v_mfma_f32_32x32x2_f32 on f32 operands.  MMEE_PREC_F32_SPLIT: the four big Linear layers of every encoder
+ * layer run on the f16 matrix cores with every f32 operand split into two f16 planes (hi + lo, 22 significant bits) and
+ * three MFMA terms per product, f32 accumulation — measured at least as accurate as the f32 MFMA chain, same
+ * 1e-4 / bit-exact parity bar; needs hidden_size and intermediate_size to be multiples of 256.  MMEE_PREC_BF16 is
+ * reserved and rejected: plain bf16 cannot meet the tolerance. */
+enum { MMEE_PREC_F32 = 0, MMEE_PREC_BF16 = 1, MMEE_PREC_F32_SPLIT = 2 };
 /* ee_load_tensor dtypes */
 enum { MMEE_DT_F32 = 0, MMEE_DT_F16 = 1, MMEE_DT_BF16 = 2 };
 /* ee_forward flags */
@@ -205,6 +210,15 @@ int ee_profile_read(ee_handle* h, int32_t idx, char* name_out, int32_t name_cap,
  * {shader cycles, 100 MHz real-time ticks} spent in the kernel, i.e. the clock the chip held (diagnostic). */
 int ee_debug_gemm(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                   int32_t K, int32_t epi, int32_t wgs_per_cu, const int32_t* row_src, uint64_t* clk_probe, void* stream);
+
+/* Unit-test / micro-benchmark hook of the split-precision GEMM (MMEE_PREC_F32_SPLIT): the f32 inputs A [rows_A, K] and
+ * W [N, K] are converted to split-f16 rows with the given power-of-two scales, then `iters` launches of the kernel compute
+ * Cout = epi(A[row_src ? row_src[r] : r] W^T + bias (+ resid)).  out_split != 0: Cout receives split-f16 rows (hi plane
+ * N f16, lo plane N f16 per row) scaled by out_scale instead of f32.  ms_out (host float, may be NULL) = average
+ * milliseconds per launch.  N % 256 == 0, K % 16 == 0. */
+int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
+                        int32_t K, int32_t epi, int32_t out_split, float a_scale, float w_scale, float out_scale,
+                        const int32_t* row_src, int32_t rows_A, int32_t iters, float* ms_out, void* stream);
 
 /* Host-only helper (no GPU needed): the relative_position_bucket LUT (HF modeling_layoutlmv3.py:392-413) over
  * delta in [-max_delta, max_delta]; out_host has 2*max_delta+1 entries, index = delta + max_delta.  Exposed so the LUT

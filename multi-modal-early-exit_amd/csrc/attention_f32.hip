@@ -242,13 +242,19 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
             const float inv = 1.0f / l_tot;
             if (qi < len) {
                 float* op = a.ctx + (size_t)(off + qi) * a.ldc + head * D + 4 * hh;
+                char* row_split = reinterpret_cast<char*>(a.ctx) + (size_t)(off + qi) * a.ldc * 4;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
                     f32x4 w0, w1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { w0[c] = o0[4 * q4 + c] * inv; w1[c] = o1[4 * q4 + c] * inv; }
-                    *reinterpret_cast<f32x4*>(op + 8 * q4) = w0;
-                    *reinterpret_cast<f32x4*>(op + 8 * q4 + 32) = w1;
+                    if (a.ctx_split) {                 // the attention-output GEMM reads split-f16 rows
+                        store_split4(row_split, a.ldc, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale);
+                        store_split4(row_split, a.ldc, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale);
+                    } else {
+                        *reinterpret_cast<f32x4*>(op + 8 * q4) = w0;
+                        *reinterpret_cast<f32x4*>(op + 8 * q4 + 32) = w1;
+                    }
                 }
             }
         }

@@ -7,6 +7,8 @@ namespace mmee {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Per-row metadata of the packed (ragged) sequence layout: what the in-kernel relative-position bias needs, in the form
 // the attention kernel consumes directly.
@@ -109,6 +111,35 @@ __device__ __forceinline__ float fast_erff(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Split-f16 operand rows (precision mode MMEE_PRECISION_F32_SPLIT, gemm_split.hip).  A row of K f32 values x[k] is kept as
+// two f16 planes in the same 4*K bytes:  bytes [0, 2K) = hi[k] = f16(s*x[k]),  bytes [2K, 4K) = lo[k] = f16(s*x[k] - hi[k]),
+// with s a power of two chosen per tensor so that the lo plane stays in the f16 normal range for every element that
+// matters (|s*x| >= 2^-3) and nothing overflows (|s*x| is clamped to 60000 < 65504).  hi + lo carries 22 significant
+// bits; the GEMM forms hi*hi + hi*lo + lo*hi on the f16 matrix cores and multiplies by 1/(s_a*s_w) (exact) afterwards.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float x = __builtin_fminf(__builtin_fmaxf(v[t] * scale, -60000.0f), 60000.0f);
+        const _Float16 h = (_Float16)x;
+        hi[t] = h;
+        lo[t] = (_Float16)(x - (float)h);
+    }
+}
+// store 4 consecutive columns [col, col+4) of a split row whose planes are `n` columns long
+__device__ __forceinline__ void store_split4(void* row_base, int n, int col, const f32x4& v, float scale) {
+    f16x4 hi, lo;
+    split_f16x4(v, scale, hi, lo);
+    char* p = reinterpret_cast<char*>(row_base);
+    *reinterpret_cast<f16x4*>(p + 2 * col) = hi;
+    *reinterpret_cast<f16x4*>(p + 2 * n + 2 * col) = lo;
+}
+// activation scales of the split planes (powers of two; see DESIGN.md "split precision")
+constexpr float kSplitScaleX = 16.0f;     // LayerNorm outputs (|x| up to a few tens)
+constexpr float kSplitScaleCtx = 64.0f;   // attention context (convex combinations of V rows)
+constexpr float kSplitScaleH1 = 16.0f;    // GELU outputs
+
+// ---------------------------------------------------------------------------------------------------------------
 // launch parameter blocks
 // ---------------------------------------------------------------------------------------------------------------
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_TANH = 3 };
@@ -134,6 +165,10 @@ struct GemmArgs {
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;
+    // split-f16 kernel (gemm_split.hip): A and W point to split rows (same row strides in bytes as f32 rows)
+    float alpha;                     // 1 / (s_a * s_w), applied to the accumulator before the bias
+    int out_split;                   // 1: C is written as split rows (planes of ldc columns) scaled by out_scale
+    float out_scale;
     int use_dma;                     // 0 = default (LDS-DMA kernel unless MMEE_GEMM_DMA=0), 1 = LDS-DMA kernel, 2 = register-staged kernel
     int prio_mode;                   // 0 none, 1 raise the priority of odd hardware wave slots, 2 of the second half of the grid
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
@@ -144,7 +179,7 @@ struct GemmArgs {
 struct AttnArgs {
     const float* qkv;            // [rows][3H], Q already divided by sqrt(d)
     int ld;
-    float* ctx;                  // [rows][H]
+    float* ctx;                  // [rows][H] f32, or split-f16 rows (ctx_split) scaled by ctx_scale
     int ldc;
     const RowMeta* meta;
     const int* doc_off;          // [n_docs + 1] dense row offsets of the active stage
@@ -155,12 +190,20 @@ struct AttnArgs {
     int n1, c1, n2, c2;
     int H, heads, max_len;
     int* item_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
+    int ctx_split;
+    float ctx_scale;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // host-side launchers (implemented next to their kernels)
 // ---------------------------------------------------------------------------------------------------------------
 void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_cus, hipStream_t s);
+void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s);
+bool gemm_split_supports(int N, int K);
+// f32 rows -> split rows (n_rows_ptr null -> n_rows_static); src row r is src[row_src ? row_src[r] : r]
+void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n_rows_static, int max_rows, int K, float scale,
+                       int num_cus, hipStream_t s);
+void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 size_t gemm_f32_lds_bytes();
 void set_gemm_wgs_per_cu(int n);

@@ -311,11 +311,13 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
     }
 }
 
-// row LayerNorm over the packed rows of the active stage: dst[r] = LN(src[row_src ? row_src[r] : r]) (dst may be src)
+// row LayerNorm over the packed rows of the active stage: dst[r] = LN(src[row_src ? row_src[r] : r]) (dst may be src or
+// null); dst_split, when given, receives the same row as split-f16 planes (the A operand of the next split GEMM)
 template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
-                                                      const float* __restrict__ g, const float* __restrict__ b, float eps) {
+                                                      const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                      char* __restrict__ dst_split, float split_scale) {
     const int n_rows = *n_rows_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
@@ -327,7 +329,14 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
             x[i] = (c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
         }
         wave_layernorm<NV>(x, H, lane, g, b, eps);
-        wave_store_row<NV>(dst + (size_t)r * H, x, H, lane);
+        if (dst) wave_store_row<NV>(dst + (size_t)r * H, x, H, lane);
+        if (dst_split) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (c < H) store_split4(dst_split + (size_t)r * H * 4, H, c, x[i], split_scale);
+            }
+        }
     }
 }
 
@@ -423,17 +432,18 @@ void launch_pool_finish(const float* part, int chunks, int H, float count, float
 }
 
 void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
-                    const float* g, const float* b, float eps, int num_cus, hipStream_t s) {
+                    const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split_v, float split_scale) {
+    char* dst_split = reinterpret_cast<char*>(dst_split_v);
     int grid = (max_rows + 3) / 4;
     const int cap = num_cus * 8;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int nv = (H + 255) / 256;
     switch (nv) {
-        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
-        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
-        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
-        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps); break;
+        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
+        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
+        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
+        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
     }
 }
 

@@ -80,7 +80,9 @@ class EarlyExitEngine:
         c.strategy = 0 if str(ec.encoder_layer_strategy) == "ramp" else 1
         c.criterion = ec.inference_strategy.code
         c.max_docs, c.max_text_len = self.max_docs, self.max_text_len
-        c.precision = {"fp32": 0, "f32": 0, "bf16": 1}[precision]
+        if precision == "auto":      # split-f16 GEMMs where the shapes allow it (hidden / intermediate sizes multiples of 256)
+            precision = "split" if (cfg.hidden_size % 256 == 0 and cfg.intermediate_size % 256 == 0) else "fp32"
+        c.precision = {"fp32": 0, "f32": 0, "bf16": 1, "split": 2, "f32_split": 2}[precision]
         self.beit = cfg.arch == "beit"
         c.arch = 1 if self.beit else 0
         c.use_abs_pos = int(cfg.use_absolute_position_embeddings)
@@ -88,7 +90,7 @@ class EarlyExitEngine:
         c.use_mean_pooling = int(cfg.use_mean_pooling)
         if self.beit:
             c.max_text_len = self.max_text_len = 0
-        self.precision = precision
+        self.precision = precision          # resolved: "fp32" or "split"
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             capi.check(self.lib.ee_create(C.byref(c), C.byref(self._h)), None, "ee_create")

@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-4
 
 
-def _engine(pkg, cfg, W, max_docs, T):
-    eng = pkg.EarlyExitEngine(cfg, max_docs=max_docs, max_text_len=T)
+def _engine(pkg, cfg, W, max_docs, T, precision="fp32"):
+    eng = pkg.EarlyExitEngine(cfg, max_docs=max_docs, max_text_len=T, precision=precision)
     eng.load_weights(W)
     return eng
 
@@ -105,12 +105,14 @@ def test_tiny_per_exit_thresholds_and_temperatures(pkg, oracle):
     eng.close()
 
 
-def test_base_shape_matches_golden(pkg):
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_base_shape_matches_golden(pkg, precision):
+    """Both GEMM back ends (f32 MFMA; split-f16 operands, 3 MFMA terms) against the same golden vectors, same tolerance."""
     g = load_golden("base_cls")
     cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
     W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
     docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
-    eng = _engine(pkg, cfg, W, max_docs=4, T=512)
+    eng = _engine(pkg, cfg, W, max_docs=4, T=512, precision=precision)
     for dense in (False, True):
         out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True,
                           dense_rows=dense, want_all=True, want_hidden_cls=True, validate=True)
@@ -123,15 +125,17 @@ def test_base_shape_matches_golden(pkg):
     eng.close()
 
 
-def test_dit_image_only_variant_matches_golden(pkg, oracle):
-    """BASELINE configs[4]: image-only DiT/BEiT through the same GEMM / attention / exit-compaction kernels."""
+@pytest.mark.parametrize("precision", ["fp32", "auto"])
+def test_dit_image_only_variant_matches_golden(pkg, oracle, precision):
+    """BASELINE configs[4]: image-only DiT/BEiT through the same GEMM / attention / exit-compaction kernels
+    ("auto" = split-f16 GEMMs at the base shape, f32 MFMA at the tiny one)."""
     from .conftest import DIT_BASE_EE, DIT_EE
     for name, mk, ee in (("dit_tiny", pkg.ModelConfig.dit_tiny, DIT_EE), ("dit_base_cls", pkg.ModelConfig.dit_base, DIT_BASE_EE)):
         g = load_golden(name)
         cfg = mk(EE_config=ee)
         W = pkg.synth.make_weights_beit(cfg, seed=int(g["seed_w"]))
         pix = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=8)["pixel_values"]
-        eng = pkg.EarlyExitEngine(cfg, max_docs=8)
+        eng = pkg.EarlyExitEngine(cfg, max_docs=8, precision=precision)
         eng.load_weights(W)
         out = eng.forward(pixel_values=pix, dump_all=True, want_all=True, want_head=True, want_hidden_cls=True, validate=True)
         np.testing.assert_allclose(_np(out.hidden_cls), g["hidden_cls"], rtol=0, atol=1e-4)
@@ -143,3 +147,46 @@ def test_dit_image_only_variant_matches_golden(pkg, oracle):
                 assert np.array_equal(_np(o2.exit_layer), g[f"pol_exits{i}"])
                 np.testing.assert_allclose(_np(o2.logits), g[f"pol_pred{i}"], rtol=0, atol=LOGIT_TOL)
         eng.close()
+
+
+def _decode_split(buf, n, scale):
+    import torch
+    h = buf.view(torch.float16).view(buf.shape[0], 2, n)
+    return (h[:, 0].double() + h[:, 1].double()) / scale
+
+
+@pytest.mark.parametrize("M,N,K,epi,out_split,gather", [
+    (1, 256, 16, 0, 0, False),          # single row, single k-step
+    (130, 256, 48, 0, 0, False),        # ragged last tile, three k-steps (ring start-up)
+    (300, 512, 768, 2, 0, True),        # residual + gathered A / residual rows (the layer after an exit)
+    (257, 1024, 256, 1, 1, False),      # GELU, split-row output (FFN-up -> FFN-down hand-over)
+    (512, 768, 3072, 3, 0, False),      # tanh, long K
+])
+def test_split_gemm_kernel_against_float64(pkg, M, N, K, epi, out_split, gather):
+    """The split-precision GEMM kernel alone: |error| vs an f64 reference no worse than 2x a plain f32 GEMM's."""
+    import ctypes as C
+    import torch
+    lib = pkg.capi.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(M * 131 + N + K)
+    rows_A = M + 40 if gather else M
+    A = torch.randn(rows_A, K, generator=gen).to(dev)
+    W = (torch.randn(N, K, generator=gen) * 0.02).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    R = torch.randn(rows_A, N, generator=gen).to(dev) if epi == 2 else None
+    rs = torch.sort(torch.randperm(rows_A, generator=gen)[:M]).values.to(torch.int32).to(dev) if gather else None
+    out = torch.full((M, N), float("nan"), device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    pkg.capi.check(lib.ee_debug_gemm_split(p(A), p(W), p(b), p(R), p(out), M, N, K, epi, out_split, 16.0, 256.0, 16.0, p(rs), rows_A, 1,
+                                           None, C.c_void_p(torch.cuda.current_stream().cuda_stream)), None, "ee_debug_gemm_split")
+    torch.cuda.synchronize()
+    Ag = A[rs.long()] if gather else A
+    ref = Ag.double() @ W.double().t() + b.double()
+    f32 = Ag @ W.t() + b
+    if epi == 1: ref, f32 = torch.nn.functional.gelu(ref), torch.nn.functional.gelu(f32)
+    if epi == 2: ref, f32 = ref + R[rs.long()].double() if gather else ref + R.double(), f32 + (R[rs.long()] if gather else R)
+    if epi == 3: ref, f32 = torch.tanh(ref), torch.tanh(f32)
+    got = _decode_split(out, N, 16.0) if out_split else out.double()
+    err = float((got - ref).abs().max())
+    err32 = float((f32.double() - ref).abs().max())
+    assert err <= max(2.0 * err32, 1e-6), (err, err32)
