@@ -213,9 +213,9 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
 
 /* Unit-test / micro-benchmark hook of the split-precision GEMM (MMEE_PREC_F32_SPLIT): the f32 inputs A [rows_A, K] and
  * W [N, K] are converted to split-f16 rows with the given power-of-two scales, then `iters` launches of the kernel compute
- * Cout = epi(A[row_src ? row_src[r] : r] W^T + bias (+ resid)).  out_split != 0: Cout receives split-f16 rows (hi plane
- * N f16, lo plane N f16 per row) scaled by out_scale instead of f32.  ms_out (host float, may be NULL) = average
- * milliseconds per launch.  N % 256 == 0, K % 16 == 0. */
+ * Cout = epi(A[row_src ? row_src[r] : r] W^T + bias (+ resid)).  out_split != 0: Cout receives split-f16 rows (64-byte
+ * groups [hi 16 f16 | lo 16 f16]) scaled by out_scale instead of f32.  ms_out (host float[2], may be NULL): [0] = average
+ * milliseconds per launch, [1] = shader clock in GHz when a diagnostic bit is set in epi (bits 4..: timing diagnostics).  N % 256 == 0, K % 16 == 0. */
 int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                         int32_t K, int32_t epi, int32_t out_split, float a_scale, float w_scale, float out_scale,
                         const int32_t* row_src, int32_t rows_A, int32_t iters, float* ms_out, void* stream);

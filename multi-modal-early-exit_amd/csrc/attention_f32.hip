@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { w0[c] = o0[4 * q4 + c] * inv; w1[c] = o1[4 * q4 + c] * inv; }
                     if (a.ctx_split) {                 // the attention-output GEMM reads split-f16 rows
-                        store_split4(row_split, a.ldc, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale);
-                        store_split4(row_split, a.ldc, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale);
+                        store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale);
+                        store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale);
                     } else {
                         *reinterpret_cast<f32x4*>(op + 8 * q4) = w0;
                         *reinterpret_cast<f32x4*>(op + 8 * q4 + 32) = w1;

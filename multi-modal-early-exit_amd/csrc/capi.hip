@@ -1049,6 +1049,8 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
 int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const float* resid, float* Cout, int32_t M, int32_t N,
                         int32_t K, int32_t epi, int32_t out_split, float a_scale, float w_scale, float out_scale,
                         const int32_t* row_src, int32_t rows_A, int32_t iters, float* ms_out, void* stream) {
+    const int dbg = epi >> 4;            // diagnostic bits (timing only): 16 no in-loop DMA, 32 no barrier, 64 no DMA wait, 128 no epilogue
+    epi &= 15;
     if (!A || !W || !Cout || M < 1 || rows_A < 1 || !mmee::gemm_split_supports(N, K) || epi < 0 || epi > 3 || iters < 1)
         return fail(nullptr, "ee_debug_gemm_split: bad argument (N %% 256, K %% 16)");
     if (epi == EPI_RESID && !resid) return fail(nullptr, "ee_debug_gemm_split: residual epilogue without a residual");
@@ -1069,7 +1071,15 @@ int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const
     GemmArgs g{};
     g.A = As; g.lda = K; g.W = Ws; g.bias = bias; g.C = Cout; g.ldc = N; g.resid = resid; g.ldr = N; g.m_static = M; g.N = N; g.K = K;
     g.scale = 1.f; g.alpha = 1.0f / (a_scale * w_scale); g.out_split = out_split ? 1 : 0; g.out_scale = out_scale;
-    g.row_src = row_src; g.resid_row_src = row_src; g.tile_counter = heads;
+    g.row_src = row_src; g.resid_row_src = row_src; g.tile_counter = heads; g.dbg_noload = dbg;
+    // diagnostic builds (any dbg bit; bit 256 = "diagnostic build, nothing removed") report the shader clock they ran at:
+    // ms_out[1] = GHz averaged over the workgroups of the last launch
+    unsigned long long* clk = nullptr;
+    const int n_clk = 2 * 2 * prop.multiProcessorCount;
+    if (dbg && ms_out) {
+        if (hipMalloc((void**)&clk, n_clk * 8) == hipSuccess) (void)hipMemsetAsync(clk, 0, n_clk * 8, s);
+        g.clk_probe = clk;
+    }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -1085,6 +1095,16 @@ int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const
     float ms = 0.f;
     if (iters > 1) (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms_out) *ms_out = iters > 1 ? ms / (float)(iters - 1) : 0.f;
+    if (clk) {
+        std::vector<unsigned long long> hc(n_clk);
+        (void)hipMemcpy(hc.data(), clk, n_clk * 8, hipMemcpyDeviceToHost);
+        double sum = 0;
+        int n = 0;
+        for (int i = 0; i + 1 < n_clk; i += 2)
+            if (hc[i + 1]) { sum += (double)hc[i] / (double)hc[i + 1] * 0.1; ++n; }
+        ms_out[1] = n ? (float)(sum / n) : 0.f;
+        (void)hipFree(clk);
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(As); (void)hipFree(Ws); (void)hipFree(heads);

@@ -111,11 +111,13 @@ __device__ __forceinline__ float fast_erff(float x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split-f16 operand rows (precision mode MMEE_PRECISION_F32_SPLIT, gemm_split.hip).  A row of K f32 values x[k] is kept as
-// two f16 planes in the same 4*K bytes:  bytes [0, 2K) = hi[k] = f16(s*x[k]),  bytes [2K, 4K) = lo[k] = f16(s*x[k] - hi[k]),
-// with s a power of two chosen per tensor so that the lo plane stays in the f16 normal range for every element that
-// matters (|s*x| >= 2^-3) and nothing overflows (|s*x| is clamped to 60000 < 65504).  hi + lo carries 22 significant
-// bits; the GEMM forms hi*hi + hi*lo + lo*hi on the f16 matrix cores and multiplies by 1/(s_a*s_w) (exact) afterwards.
+// Split-f16 operand rows (precision mode MMEE_PREC_F32_SPLIT, gemm_split.hip).  A row of K f32 values x[k] is kept in the same
+// 4*K bytes as K/16 groups of 64 bytes: group j = [hi[16j .. 16j+15] (32 B) | lo[16j .. 16j+15] (32 B)] with
+// hi[k] = f16(s*x[k]), lo[k] = f16(s*x[k] - hi[k]) and s a power of two chosen per tensor so that the lo plane stays in the
+// f16 normal range for every element that matters (|s*x| >= 2^-3) and nothing overflows (|s*x| is clamped to 60000 <
+// 65504).  hi + lo carries 22 significant bits; the GEMM forms hi*hi + hi*lo + lo*hi on the f16 matrix cores and multiplies
+// by 1/(s_a*s_w) (exact) afterwards.  A group is one MFMA k-step of both planes, so the GEMM's global -> LDS pieces read
+// whole contiguous 64-byte runs.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& hi, f16x4& lo) {
 #pragma unroll
@@ -126,13 +128,13 @@ __device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& 
         lo[t] = (_Float16)(x - (float)h);
     }
 }
-// store 4 consecutive columns [col, col+4) of a split row whose planes are `n` columns long
-__device__ __forceinline__ void store_split4(void* row_base, int n, int col, const f32x4& v, float scale) {
+// store 4 consecutive columns [col, col+4) (col % 4 == 0) of a split row
+__device__ __forceinline__ void store_split4(void* row_base, int col, const f32x4& v, float scale) {
     f16x4 hi, lo;
     split_f16x4(v, scale, hi, lo);
-    char* p = reinterpret_cast<char*>(row_base);
-    *reinterpret_cast<f16x4*>(p + 2 * col) = hi;
-    *reinterpret_cast<f16x4*>(p + 2 * n + 2 * col) = lo;
+    char* p = reinterpret_cast<char*>(row_base) + (col >> 4) * 64 + (col & 15) * 2;
+    *reinterpret_cast<f16x4*>(p) = hi;
+    *reinterpret_cast<f16x4*>(p + 32) = lo;
 }
 // activation scales of the split planes (powers of two; see DESIGN.md "split precision")
 constexpr float kSplitScaleX = 16.0f;     // LayerNorm outputs (|x| up to a few tens)

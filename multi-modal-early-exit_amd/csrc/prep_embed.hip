@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < H) store_split4(dst_split + (size_t)r * H * 4, H, c, x[i], split_scale);
+                if (c < H) store_split4(dst_split + (size_t)r * H * 4, c, x[i], split_scale);
             }
         }
     }

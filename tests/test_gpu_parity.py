@@ -151,13 +151,13 @@ def test_dit_image_only_variant_matches_golden(pkg, oracle, precision):
 
 def _decode_split(buf, n, scale):
     import torch
-    h = buf.view(torch.float16).view(buf.shape[0], 2, n)
-    return (h[:, 0].double() + h[:, 1].double()) / scale
+    h = buf.view(torch.float16).view(buf.shape[0], n // 16, 2, 16)      # 64-byte groups [hi 16 | lo 16]
+    return (h[:, :, 0].double() + h[:, :, 1].double()).reshape(buf.shape[0], n) / scale
 
 
 @pytest.mark.parametrize("M,N,K,epi,out_split,gather", [
-    (1, 256, 16, 0, 0, False),          # single row, single k-step
-    (130, 256, 48, 0, 0, False),        # ragged last tile, three k-steps (ring start-up)
+    (1, 256, 32, 0, 0, False),          # single row, single k-stage
+    (130, 256, 96, 0, 0, False),        # ragged last tile, three k-stages (ring start-up)
     (300, 512, 768, 2, 0, True),        # residual + gathered A / residual rows (the layer after an exit)
     (257, 1024, 256, 1, 1, False),      # GELU, split-row output (FFN-up -> FFN-down hand-over)
     (512, 768, 3072, 3, 0, False),      # tanh, long K

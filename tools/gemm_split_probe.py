@@ -15,21 +15,21 @@ p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
 def decode_split(buf, N, scale):
     """[M, N] f32-sized rows holding (hi N f16 | lo N f16) -> f64 values"""
-    h = buf.view(torch.float16).view(buf.shape[0], 2, N)
-    return (h[:, 0].double() + h[:, 1].double()) / scale
+    h = buf.view(torch.float16).view(buf.shape[0], N // 16, 2, 16)      # 64-byte groups [hi 16 | lo 16]
+    return (h[:, :, 0].double() + h[:, :, 1].double()).reshape(buf.shape[0], N) / scale
 
 
 def run(M, N, K, epi=0, out_split=0, iters=1, check=False, fold=0, a_std=1.0):
     A = torch.randn(M, K, device=dev) * a_std
     W = torch.randn(N, K, device=dev) * 0.02
     b = torch.randn(N, device=dev)
-    R = torch.randn(M, N, device=dev) if epi == 2 else None
+    R = torch.randn(M, N, device=dev) if (epi & 15) == 2 else None
     Cc = torch.zeros(M, N, device=dev)
     rs = ((torch.arange(M, device=dev, dtype=torch.int32) * 3) // 4).contiguous() if fold else None
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ms = C.c_float(0)
+    ms = (C.c_float * 2)(0, 0)
     pkg.capi.check(lib.ee_debug_gemm_split(p(A), p(W), p(b), p(R), p(Cc), M, N, K, epi, out_split, 16.0, 256.0, 16.0, p(rs), M, iters,
-                                           C.byref(ms), st), None, "gemm_split")
+                                           ms, st), None, "gemm_split")
     torch.cuda.synchronize()
     if check:
         Ad = (A[rs.long()] if fold else A).double()
@@ -45,9 +45,10 @@ def run(M, N, K, epi=0, out_split=0, iters=1, check=False, fold=0, a_std=1.0):
         print(f"  M={M} N={N} K={K} epi={epi} out_split={out_split} fold={fold}: max |err| vs f64 {float((got - ref).abs().max()):.3e}"
               f"   (torch f32 GEMM: {float((f32.double() - ref).abs().max()):.3e})", flush=True)
     if iters > 1:
-        tf = 2.0 * M * N * K / ms.value / 1e9
-        print(f"M={M} N={N} K={K} epi={epi} out_split={out_split}: {ms.value:.3f} ms  {tf:.1f} TFLOP/s algorithmic "
-              f"({tf / 157.3:.2f} x the f32 MFMA peak, {tf / (2500 / 3):.1%} of f16 peak / 3)", flush=True)
+        tf = 2.0 * M * N * K / ms[0] / 1e9
+        clk = f", clock {ms[1]:.2f} GHz -> {tf / (2500 / 3 * ms[1] / 2.4):.1%} of the peak at that clock" if ms[1] else ""
+        print(f"M={M} N={N} K={K} epi={epi} out_split={out_split}: {ms[0]:.3f} ms  {tf:.1f} TFLOP/s algorithmic "
+              f"({tf / 157.3:.2f} x the f32 MFMA peak, {tf / (2500 / 3):.1%} of f16 peak / 3{clk})", flush=True)
 
 
 if __name__ == "__main__":
