@@ -792,15 +792,15 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             GemmArgs g{};
             { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX); }
             g.A = h->CTX; g.lda = H; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
-            g.alpha = w.qkv_inv / mmee::kSplitScaleX;
+            g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
             g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
             { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
             AttnArgs at{};
             at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
             at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
             at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
-            at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx;
-            { ProfScope ps(h, P_ATTN, s); launch_attention_f32(at, B, cus, s); }
+            at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
+            { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
             g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
             g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
@@ -821,15 +821,15 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         GemmArgs g{};
         // QKV projection, Q pre-divided by sqrt(d) (HF:263)
         g.A = sp ? h->Xs : h->X; g.lda = H; g.row_src = rs; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
-        g.alpha = w.qkv_inv / mmee::kSplitScaleX;
+        g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
         g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
         { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
         AttnArgs at{};
         at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
         at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
         at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
-        at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx;
-        { ProfScope ps(h, P_ATTN, s); launch_attention_f32(at, B, cus, s); }
+        at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
+        { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;

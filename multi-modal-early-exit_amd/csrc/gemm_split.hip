@@ -302,7 +302,7 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
 // epilogue, CfgB otherwise.
 void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : 0) : 0; }();
-    const bool use_a = forced ? forced == 1 : (epi == EPI_GELU || a.out_split);
+    const bool use_a = forced ? forced == 1 : epi == EPI_GELU;
     if (a.dbg_noload) {      // timing diagnostics: only the two shapes the probes use
         if (a.out_split) launch_split_one<CfgA, EPI_GELU, true, true>(a, max_m, num_cus, s);
         else if (use_a) launch_split_one<CfgA, EPI_RESID, false, true>(a, max_m, num_cus, s);
@@ -311,7 +311,8 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
     }
     if (a.out_split) {
         if (epi == EPI_GELU) launch_split_one<CfgA, EPI_GELU, true>(a, max_m, num_cus, s);
-        else launch_split_one<CfgA, EPI_BIAS, true>(a, max_m, num_cus, s);
+        else if (use_a) launch_split_one<CfgA, EPI_BIAS, true>(a, max_m, num_cus, s);
+        else launch_split_one<CfgB, EPI_BIAS, true>(a, max_m, num_cus, s);      // QKV projection -> split Q | K | V rows
         return;
     }
     if (use_a) {

@@ -140,6 +140,7 @@ __device__ __forceinline__ void store_split4(void* row_base, int col, const f32x
 constexpr float kSplitScaleX = 16.0f;     // LayerNorm outputs (|x| up to a few tens)
 constexpr float kSplitScaleCtx = 64.0f;   // attention context (convex combinations of V rows)
 constexpr float kSplitScaleH1 = 16.0f;    // GELU outputs
+constexpr float kSplitScaleQKV = 16.0f;   // Q / sqrt(d), K, V
 
 // ---------------------------------------------------------------------------------------------------------------
 // launch parameter blocks
@@ -194,6 +195,7 @@ struct AttnArgs {
     int* item_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
     int ctx_split;
     float ctx_scale;
+    float qkv_scale;                 // attention_split.hip: scale of the split Q | K | V rows (qkv then points to split rows)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -207,6 +209,7 @@ void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n
                        int num_cus, hipStream_t s);
 void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
+void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 size_t gemm_f32_lds_bytes();
 void set_gemm_wgs_per_cu(int n);
 void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s);   // diagnostic build with in-kernel stamps
