@@ -80,7 +80,7 @@ def calibrate_thresholds(conf, release):
     return thr
 
 
-def measure_hbm_traffic(thr, batch, kernel_substr="gemm_f32_kernel<1, 0", timeout=240):
+def measure_hbm_traffic(thr, batch, kernel_substr, precision, timeout=240):
     """HBM bytes per launch of the dominant kernel from the PMC counters, as MI355X_MICROARCH.md (HBM section)
     prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (TCC slots), both in KiB; on gfx950
     FETCH_SIZE reports half of the bytes of wide coalesced streaming reads, so it is doubled; WRITE_SIZE is exact for
@@ -95,7 +95,7 @@ def measure_hbm_traffic(thr, batch, kernel_substr="gemm_f32_kernel<1, 0", timeou
         d = tempfile.mkdtemp(prefix="mmee_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic",
-               "--batch", str(batch), "--thresholds", ",".join(repr(float(t)) for t in thr[:-1])]
+               "--batch", str(batch), "--precision", precision, "--thresholds", ",".join(repr(float(t)) for t in thr[:-1])]
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             env.pop(k, None)
@@ -290,7 +290,9 @@ def main():
         line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
         fl2 = eng.flops()
         if world == 1 and not a.no_traffic:
-            tb, detail = measure_hbm_traffic(thr, B)
+            # kernel-name fragments of the FFN-up launches as rocprofv3 prints them
+            ksub = "SplitCfg<128, 256, 64, 3, 2, 4, 2>, 1, true" if split else "gemm_f32_dma_kernel<1, 0"
+            tb, detail = measure_hbm_traffic(thr, B, ksub, eng.precision)
             line["roofline"]["traffic"] = tb
             line["roofline"]["traffic_detail"] = detail
             if tb:

@@ -36,11 +36,13 @@ namespace mmee {
 
 // Tile configurations.  ROWB = bytes of one LDS row = one k-stage of one operand row: 64 (k = 16: [hi 16 | lo 16]) or
 // 128 (k = 32: two such groups).  Each wave owns a 64x64 sub-tile (2x2 MFMA tiles); WM x WN waves per workgroup.
-//   CfgA  128x256, k16 stages, 3-deep ring (72 KiB), 8 waves, 2 workgroups per CU — the FFN-up GEMM: its GELU + split
-//         epilogue is ~35 VALU instructions per element and must run under another workgroup's MFMA stream.
-//   CfgB  256x256, k32 stages, 2-deep ring (128 KiB), 16 waves, 1 workgroup per CU — every other big GEMM: whole 128-byte
-//         lines per DMA row (half the L2 requests per byte of CfgA, which rocprof showed at 43 % of the L2 request slots)
-//         and a third less global -> LDS traffic per MAC; the light epilogue is exposed (~5 % at K = 768).
+//   CfgA  128x256, k16 stages, 3-deep ring (72 KiB), 8 waves, 2 workgroups per CU: one workgroup's epilogue runs under the
+//         other's MFMA stream, at the price of 64-byte DMA rows.
+//   CfgB  256x256, k32 stages, 2-deep ring (128 KiB), 16 waves, 1 workgroup per CU (default): whole 128-byte lines per
+//         DMA row (half the L2 requests per byte of CfgA, which rocprof showed at 43 % of the L2 request slots) and a third
+//         less global -> LDS traffic per MAC; the epilogue is exposed but the kernel is power-limited (shader clock
+//         1.35-1.6 GHz under f16 MFMA load), so the energy saved on data movement wins: 390 vs 362 TFLOP/s on the
+//         bias epilogue, 317 vs 297 on GELU + split output (tools/gemm_split_epi.py).
 template <int BM_, int BN_, int ROWB_, int NST_, int WM_, int WN_, int WGS_>
 struct SplitCfg {
     static constexpr int BM = BM_, BN = BN_, ROWB = ROWB_, NST = NST_, WM = WM_, WN = WN_, WGS = WGS_;
@@ -100,20 +102,42 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
             f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + c4);
             if (row < M) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float x = fmaf(v[t], alpha, bv[t]) * sc;
-                    if (EPI == EPI_GELU) x = x * 0.5f * (1.0f + fast_erff(x * 0.70710678118654752440f));
-                    if (EPI == EPI_TANH) x = tanhf(x);
-                    v[t] = x * lam[t];
+                for (int t = 0; t < 4; t += 2) {      // two columns at a time: packed f32 VALU
+                    f32x2 x = __builtin_elementwise_fma(f32x2{v[t], v[t + 1]}, (f32x2)(alpha), f32x2{bv[t], bv[t + 1]}) * (f32x2)(sc);
+                    if (EPI == EPI_GELU) x = gelu_erf2(x);
+                    if (EPI == EPI_TANH) { x[0] = tanhf(x[0]); x[1] = tanhf(x[1]); }
+                    x = x * f32x2{lam[t], lam[t + 1]};
+                    v[t] = x[0];
+                    v[t + 1] = x[1];
                 }
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
                     v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
                 }
-                if (OUT_SPLIT)
-                    store_split4(reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4, col, v, g.out_scale);
-                else
-                    *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+                if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+            }
+            if (OUT_SPLIT) {
+                // The four lanes of a quad hold columns 4q .. 4q+3 of one 16-column group, whose 64 output bytes are
+                // [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]: a quad permute hands lane q the 16-byte piece number q, so the
+                // row leaves as one fully coalesced 16-byte-per-lane store (as the f32 output does) instead of two 8-byte
+                // scatters per lane.  Every lane takes part in the permute (rows >= M only skip the store).
+                f16x4 hi, lo;
+                split_f16x4(v, g.out_scale, hi, lo);
+                const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
+                const bool take_lo = (lane & 2) != 0;
+                int4 piece;       // lane q: q = 0 -> hi of lanes 0,1; 1 -> hi of lanes 2,3; 2 -> lo of lanes 0,1; 3 -> lo of lanes 2,3
+                {
+                    const int a0 = __builtin_amdgcn_mov_dpp(h2.x, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp(h2.y, 0x88, 0xf, 0xf, true);
+                    const int b0 = __builtin_amdgcn_mov_dpp(l2.x, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp(l2.y, 0x88, 0xf, 0xf, true);
+                    const int c0 = __builtin_amdgcn_mov_dpp(h2.x, 0xDD, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp(h2.y, 0xDD, 0xf, 0xf, true);
+                    const int d0 = __builtin_amdgcn_mov_dpp(l2.x, 0xDD, 0xf, 0xf, true), d1 = __builtin_amdgcn_mov_dpp(l2.y, 0xDD, 0xf, 0xf, true);
+                    piece.x = take_lo ? b0 : a0;
+                    piece.y = take_lo ? b1 : a1;
+                    piece.z = take_lo ? d0 : c0;
+                    piece.w = take_lo ? d1 : c1;
+                }
+                if (row < M)
+                    *reinterpret_cast<int4*>(reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4 + (size_t)(col >> 4) * 64 + (lane & 3) * 16) = piece;
             }
         }
     }
@@ -298,11 +322,11 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
     hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
 }
 
-// MMEE_SPLIT_CFG=A / B forces one tile configuration for every GEMM (A/B measurements); default: CfgA for the GELU
-// epilogue, CfgB otherwise.
+// CfgB is the default for every GEMM (measured end to end: 5378 vs 5283 docs/s with CfgA for the GELU GEMM);
+// MMEE_SPLIT_CFG=A forces CfgA (A/B measurements).
 void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : 0) : 0; }();
-    const bool use_a = forced ? forced == 1 : epi == EPI_GELU;
+    const bool use_a = forced == 1;
     if (a.dbg_noload) {      // timing diagnostics: only the two shapes the probes use
         if (a.out_split) launch_split_one<CfgA, EPI_GELU, true, true>(a, max_m, num_cus, s);
         else if (use_a) launch_split_one<CfgA, EPI_RESID, false, true>(a, max_m, num_cus, s);
@@ -310,7 +334,8 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
         return;
     }
     if (a.out_split) {
-        if (epi == EPI_GELU) launch_split_one<CfgA, EPI_GELU, true>(a, max_m, num_cus, s);
+        if (epi == EPI_GELU && use_a) launch_split_one<CfgA, EPI_GELU, true>(a, max_m, num_cus, s);
+        else if (epi == EPI_GELU) launch_split_one<CfgB, EPI_GELU, true>(a, max_m, num_cus, s);
         else if (use_a) launch_split_one<CfgA, EPI_BIAS, true>(a, max_m, num_cus, s);
         else launch_split_one<CfgB, EPI_BIAS, true>(a, max_m, num_cus, s);      // QKV projection -> split Q | K | V rows
         return;
@@ -326,6 +351,7 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
     }
     switch (epi) {
         case EPI_BIAS: launch_split_one<CfgB, EPI_BIAS, false>(a, max_m, num_cus, s); break;
+        case EPI_GELU: launch_split_one<CfgB, EPI_GELU, false>(a, max_m, num_cus, s); break;
         case EPI_RESID: launch_split_one<CfgB, EPI_RESID, false>(a, max_m, num_cus, s); break;
         default: launch_split_one<CfgB, EPI_TANH, false>(a, max_m, num_cus, s); break;
     }

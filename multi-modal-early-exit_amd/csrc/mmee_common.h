@@ -5,6 +5,7 @@
 
 namespace mmee {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -110,6 +111,32 @@ __device__ __forceinline__ float fast_erff(float x) {
     return copysignf(r, x);
 }
 
+// Two-wide forms of the same arithmetic: on gfx950 the compiler turns f32x2 multiply / add / fma into v_pk_mul_f32 /
+// v_pk_add_f32 / v_pk_fma_f32 (two f32 results per lane per instruction at the one-result issue cost), which halves the
+// VALU time of the epilogues that hang ~25 such operations on every output element.  Bitwise identical to fast_erff.
+__device__ __forceinline__ f32x2 fast_erf2(f32x2 x) {
+    const f32x2 a = __builtin_elementwise_min(__builtin_elementwise_abs(x), (f32x2)(4.0f));
+    f32x2 q = (f32x2)(5.389074067e-05f);
+    q = __builtin_elementwise_fma(q, a, (f32x2)(-5.102792056e-04f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(1.682463451e-03f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(4.861298949e-04f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(-2.802465111e-02f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(1.483877152e-01f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(9.184340239e-01f));
+    q = __builtin_elementwise_fma(q, a, (f32x2)(1.627907515e+00f));
+    q = q * a;
+    f32x2 r;
+    r[0] = 1.0f - __builtin_amdgcn_exp2f(-q[0]);
+    r[1] = 1.0f - __builtin_amdgcn_exp2f(-q[1]);
+    r[0] = copysignf(r[0], x[0]);
+    r[1] = copysignf(r[1], x[1]);
+    return r;
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // x * 0.5 * (1 + erf(x / sqrt 2)), same operation order as the scalar form
+    const f32x2 e = fast_erf2(x * (f32x2)(0.70710678118654752440f));
+    return (x * (f32x2)(0.5f)) * ((f32x2)(1.0f) + e);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Split-f16 operand rows (precision mode MMEE_PREC_F32_SPLIT, gemm_split.hip).  A row of K f32 values x[k] is kept in the same
 // 4*K bytes as K/16 groups of 64 bytes: group j = [hi[16j .. 16j+15] (32 B) | lo[16j .. 16j+15] (32 B)] with
@@ -119,13 +146,17 @@ __device__ __forceinline__ float fast_erff(float x) {
 // by 1/(s_a*s_w) (exact) afterwards.  A group is one MFMA k-step of both planes, so the GEMM's global -> LDS pieces read
 // whole contiguous 64-byte runs.
 // ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& hi, f16x4& lo) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float x = __builtin_fminf(__builtin_fmaxf(v[t] * scale, -60000.0f), 60000.0f);
-        const _Float16 h = (_Float16)x;
-        hi[t] = h;
-        lo[t] = (_Float16)(x - (float)h);
+    for (int t = 0; t < 4; t += 2) {          // pairs: v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32
+        f32x2 x = f32x2{v[t], v[t + 1]} * (f32x2)(scale);
+        x = __builtin_elementwise_min(__builtin_elementwise_max(x, (f32x2)(-60000.0f)), (f32x2)(60000.0f));
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 hf = __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(x - hf, f16x2);
+        hi[t] = h[0]; hi[t + 1] = h[1];
+        lo[t] = l[0]; lo[t + 1] = l[1];
     }
 }
 // store 4 consecutive columns [col, col+4) (col % 4 == 0) of a split row
