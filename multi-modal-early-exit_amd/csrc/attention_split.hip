@@ -17,6 +17,7 @@
 //     and for the transposed reads of V (cdna_hip_programming.md T10, image (b)).
 //   * bias / mask / softmax are unchanged f32 VALU work (three LDS table lookups per score); the score gets its
 //     1/(s_q s_k) de-scaling in the same fused multiply-add that adds the bias.
+#include <cstdlib>
 #include "mmee_common.h"
 
 namespace mmee {
@@ -41,7 +42,8 @@ static size_t attn_split_lds_bytes(const AttnArgs& a) {
     return 2 * (size_t)TILE_BYTES + (size_t)KT * sizeof(RowMeta) + ((size_t)a.n1 + 2 * (size_t)a.n2 + 4) * sizeof(float);
 }
 
-__global__ __launch_bounds__(256, 3) void attention_split_kernel(const AttnArgs a) {
+template <int WGS>
+__global__ __launch_bounds__(256, WGS) void attention_split_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* Ks = reinterpret_cast<char*>(smem);          // [KT][256 B]
     char* Vs = Ks + TILE_BYTES;
@@ -194,44 +196,60 @@ __global__ __launch_bounds__(256, 3) void attention_split_kernel(const AttnArgs 
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[st], s, 0, 0, 0);
                 }
                 // ---- bias, mask, online softmax.  register e <-> key (e&3) + 8*(e>>2) + 4*hh of the tile ---------
+                // (two registers at a time: f32x2 arithmetic compiles to v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
                 float tmax = kMasked;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const RowMeta mk = Ms[kl];
-                    const float b1 = *reinterpret_cast<const float*>(t1q + mk.pos);
-                    const float bx = *reinterpret_cast<const float*>(txq + mk.x0);
-                    const float by = *reinterpret_cast<const float*>(tyq + mk.y1);
-                    const float bias = b1 + (bx + by);              // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455
-                    const float v = fmaf(s[e], inv_qk, bias) + __int_as_float(mk.flags);
-                    s[e] = v;
-                    tmax = fmaxf(tmax, v);
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 bias, mask;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int kl = ((e + t) & 3) + 8 * ((e + t) >> 2) + 4 * hh;
+                        const RowMeta mk = Ms[kl];
+                        const float b1 = *reinterpret_cast<const float*>(t1q + mk.pos);
+                        const float bx = *reinterpret_cast<const float*>(txq + mk.x0);
+                        const float by = *reinterpret_cast<const float*>(tyq + mk.y1);
+                        bias[t] = b1 + (bx + by);                   // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455
+                        mask[t] = __int_as_float(mk.flags);
+                    }
+                    const f32x2 v = __builtin_elementwise_fma(f32x2{s[e], s[e + 1]}, (f32x2)(inv_qk), bias) + mask;
+                    s[e] = v[0];
+                    s[e + 1] = v[1];
+                    tmax = fmaxf(tmax, fmaxf(v[0], v[1]));
                 }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float m_new = fmaxf(m_run, tmax);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-                float psum = 0.f;
+                f32x2 psum2 = f32x2{0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float p = __builtin_amdgcn_exp2f((s[e] - m_new) * kLog2e);
-                    s[e] = p;
-                    psum += p;
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 x = (f32x2{s[e], s[e + 1]} - (f32x2)(m_new)) * (f32x2)(kLog2e);
+                    f32x2 p;
+                    p[0] = __builtin_amdgcn_exp2f(x[0]);
+                    p[1] = __builtin_amdgcn_exp2f(x[1]);
+                    s[e] = p[0];
+                    s[e + 1] = p[1];
+                    psum2 += p;
                 }
-                l_run = l_run * alpha + psum;
+                l_run = l_run * alpha + (psum2[0] + psum2[1]);
                 m_run = m_new;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 a0 = f32x2{o0[e], o0[e + 1]} * (f32x2)(alpha), a1 = f32x2{o1[e], o1[e + 1]} * (f32x2)(alpha);
+                    o0[e] = a0[0]; o0[e + 1] = a0[1];
+                    o1[e] = a1[0]; o1[e + 1] = a1[1];
+                }
                 // ---- O^T += V^T P^T.  B operand = P^T: for k-step st, element j of lane (query, hh) is register 8 st + j, i.e.
                 // key 16 st + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads ----
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     f16x8 ph, pl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = s[8 * st + j] * kPScale;
-                        const _Float16 h = (_Float16)x;
-                        ph[j] = h;
-                        pl[j] = (_Float16)(x - (float)h);
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2 x = f32x2{s[8 * st + j], s[8 * st + j + 1]} * (f32x2)(kPScale);
+                        const f16x2 h = __builtin_convertvector(x, f16x2);
+                        const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+                        ph[j] = h[0]; ph[j + 1] = h[1];
+                        pl[j] = l[0]; pl[j + 1] = l[1];
                     }
 #pragma unroll
                     for (int dh = 0; dh < 2; ++dh) {
@@ -286,19 +304,22 @@ __global__ __launch_bounds__(256, 3) void attention_split_kernel(const AttnArgs 
 }
 
 void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
+    // MMEE_ATTN_WGS=2: 256-VGPR build at two workgroups per CU (A/B switch); default three workgroups per CU
+    static const int wgs = [] { const char* e = getenv("MMEE_ATTN_WGS"); return (e && e[0] == '2') ? 2 : 3; }();
     static bool attr_set = false;
     const size_t lds = attn_split_lds_bytes(a);
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_split_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_split_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
-    int grid = 3 * num_cus;
+    int grid = wgs * num_cus;
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(attention_split_kernel, dim3(grid), dim3(256), lds, s, a);
+    if (wgs == 2) hipLaunchKernelGGL(attention_split_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(attention_split_kernel<3>, dim3(grid), dim3(256), lds, s, a);
 }
 
 }  // namespace mmee

@@ -43,9 +43,11 @@ namespace mmee {
 //         less global -> LDS traffic per MAC; the epilogue is exposed but the kernel is power-limited (shader clock
 //         1.35-1.6 GHz under f16 MFMA load), so the energy saved on data movement wins: 390 vs 362 TFLOP/s on the
 //         bias epilogue, 317 vs 297 on GELU + split output (tools/gemm_split_epi.py).
-template <int BM_, int BN_, int ROWB_, int NST_, int WM_, int WN_, int WGS_>
+template <int BM_, int BN_, int ROWB_, int NST_, int WM_, int WN_, int WGS_, int MF_ = 32>
 struct SplitCfg {
     static constexpr int BM = BM_, BN = BN_, ROWB = ROWB_, NST = NST_, WM = WM_, WN = WN_, WGS = WGS_;
+    static constexpr int MF = MF_;                               // MFMA shape: 32 = 32x32x16, 16 = 16x16x32 (needs ROWB = 128)
+    static_assert(MF == 32 || (MF == 16 && ROWB == 128), "the 16x16x32 MFMA consumes one 128-byte row (k = 32) per step");
     static constexpr int NW = WM * WN, THREADS = NW * 64;
     static constexpr int KSTAGE = ROWB / 4;                      // k values per stage (16 or 32)
     static constexpr int PROWS = 1024 / ROWB;                    // rows per 1 KiB DMA piece (16 or 8)
@@ -60,6 +62,10 @@ struct SplitCfg {
 };
 using CfgA = SplitCfg<128, 256, 64, 3, 2, 4, 2>;
 using CfgB = SplitCfg<256, 256, 128, 2, 4, 4, 1>;
+// CfgC = CfgB on v_mfma_f32_16x16x32_f16.  The kernel is power-limited (tools/mfma_f16_peak.hip: a bare 32x32x16 loop on
+// random operands holds 1.62 GHz = 1674 TFLOP/s, a bare 16x16x32 loop 1.89 GHz = 1945 TFLOP/s): the 16x16x32 form moves
+// half the accumulator bits per MAC, and the clock the chip can hold rises with it.
+using CfgC = SplitCfg<256, 256, 128, 2, 4, 4, 1, 16>;
 
 bool gemm_split_supports(int N, int K) { return N > 0 && K > 0 && N % 256 == 0 && K % 32 == 0; }
 
@@ -143,6 +149,79 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
     }
 }
 
+// Accumulator staging of the 16x16x32 form: tile (mi, ni) of the wave's 4x4 has col = lane & 15, rows 4 (lane >> 4) + reg.
+// One 32-row half (mi = 2 half, 2 half + 1) is written to the wave's [32][64] f32 staging block; the column index is XOR-ed with
+// 16 on rows whose (row >> 2) is odd, so the two 16-lane groups of a 32-lane write group hit disjoint banks.
+template <int EPI, bool OUT_SPLIT, int WN>
+__device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* smem, f32x4 (&acc)[4][4], int m0, int n0, int M,
+                                                   int wave, int lane) {
+    const int wr = wave / WN, wc = wave % WN;
+    const int l15 = lane & 15, gq = lane >> 4;
+    float* stg = smem + wave * (32 * 64);
+    const int c4 = (lane & 15) * 4;
+    const int col = n0 + wc * 64 + c4;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+    const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
+    f32x4 lam = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
+    const float alpha = g.alpha;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 16 * m2 + 4 * gq + e;                      // (r >> 2) & 1 == gq & 1
+                    stg[r * 64 + ((ni * 16 + l15) ^ (16 * (gq & 1)))] = acc[2 * half + m2][ni][e];
+                }
+        const int rbase = m0 + wr * 64 + half * 32 + (lane >> 4);
+#pragma unroll 4
+        for (int j = 0; j < 8; ++j) {
+            const int rl = (lane >> 4) + 4 * j;
+            const int row = rbase + 4 * j;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (c4 ^ (16 * ((rl >> 2) & 1))));
+            if (row < M) {
+#pragma unroll
+                for (int t = 0; t < 4; t += 2) {
+                    f32x2 x = __builtin_elementwise_fma(f32x2{v[t], v[t + 1]}, (f32x2)(alpha), f32x2{bv[t], bv[t + 1]}) * (f32x2)(sc);
+                    if (EPI == EPI_GELU) x = gelu_erf2(x);
+                    if (EPI == EPI_TANH) { x[0] = tanhf(x[0]); x[1] = tanhf(x[1]); }
+                    x = x * f32x2{lam[t], lam[t + 1]};
+                    v[t] = x[0];
+                    v[t + 1] = x[1];
+                }
+                if (EPI == EPI_RESID) {
+                    const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
+                    v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                }
+                if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+            }
+            if (OUT_SPLIT) {
+                f16x4 hi, lo;
+                split_f16x4(v, g.out_scale, hi, lo);
+                const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
+                const bool take_lo = (lane & 2) != 0;
+                int4 piece;
+                {
+                    const int a0 = __builtin_amdgcn_mov_dpp(h2.x, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp(h2.y, 0x88, 0xf, 0xf, true);
+                    const int b0 = __builtin_amdgcn_mov_dpp(l2.x, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp(l2.y, 0x88, 0xf, 0xf, true);
+                    const int c0 = __builtin_amdgcn_mov_dpp(h2.x, 0xDD, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp(h2.y, 0xDD, 0xf, 0xf, true);
+                    const int d0 = __builtin_amdgcn_mov_dpp(l2.x, 0xDD, 0xf, 0xf, true), d1 = __builtin_amdgcn_mov_dpp(l2.y, 0xDD, 0xf, 0xf, true);
+                    piece.x = take_lo ? b0 : a0;
+                    piece.y = take_lo ? b1 : a1;
+                    piece.z = take_lo ? d0 : c0;
+                    piece.w = take_lo ? d1 : c1;
+                }
+                if (row < M)
+                    *reinterpret_cast<int4*>(reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4 + (size_t)(col >> 4) * 64 + (lane & 3) * 16) = piece;
+            }
+        }
+    }
+}
+
 template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false>
 __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmArgs g) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, ROWB = Cfg::ROWB, NST = Cfg::NST, WN = Cfg::WN, PA = Cfg::PA, PW = Cfg::PW;
@@ -182,6 +261,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     const unsigned rswz = ROWB == 64 ? (unsigned)((l31 >> 2) & 3) : (unsigned)((l31 >> 1) & 7);
     const unsigned a_row = (unsigned)(wr * 64 + l31) * ROWB;
     const unsigned w_row = (unsigned)A_BYTES + (unsigned)(wc * 64 + l31) * ROWB;
+    // 16x16x32 form: lane (r = lane & 15, q = lane >> 4) takes k = 8q .. 8q+7 of the 32: logical chunks (q & 1) + 4 (q >> 1)
+    // (hi) and + 2 (lo) of row r of a 16-row tile; the row XOR only sees (r >> 1) & 7 (tiles start at multiples of 16)
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned swz16 = (unsigned)((l15 >> 1) & 7);
+    const unsigned c16_hi = 16u * (((unsigned)(lq & 1) + 4u * (unsigned)(lq >> 1)) ^ swz16);
+    const unsigned c16_lo = 16u * (((unsigned)(lq & 1) + 4u * (unsigned)(lq >> 1) + 2u) ^ swz16);
+    const unsigned a_row16 = (unsigned)(wr * 64 + l15) * ROWB;
+    const unsigned w_row16 = (unsigned)A_BYTES + (unsigned)(wc * 64 + l15) * ROWB;
     const char* sbytes = reinterpret_cast<const char*>(smem);
 
     for (;; tile += gridDim.x) {
@@ -246,12 +333,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
         };
 
         f32x16 acc[2][2];
+        f32x4 acc16[4][4];
+        if constexpr (Cfg::MF == 32) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
         // ring: stage kt lives in slot kt % NST; NST - 1 stages are in flight ahead of the one being consumed
         issue(0, 0);
@@ -272,6 +367,26 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             }
             if (kt + NST - 1 < nk && !(dbg & 1)) issue(kt + NST - 1, bufn);
             const char* sb = sbytes + buf * STAGE_BYTES;
+            if constexpr (Cfg::MF == 16) {
+                // A fragments of the four 16-row tiles stay in registers; W fragments come one 16-column tile at a time
+                f16x8 ah[4], al[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(sb + a_row16 + c16_hi + i * 16 * ROWB);
+                    al[i] = *reinterpret_cast<const f16x8*>(sb + a_row16 + c16_lo + i * 16 * ROWB);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(sb + w_row16 + c16_hi + j * 16 * ROWB);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(sb + w_row16 + c16_lo + j * 16 * ROWB);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc16[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc16[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh, acc16[i][j], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int ks = 0; ks < ROWB / 64; ++ks) {
                 const unsigned c_hi = 16u * (((unsigned)(4 * ks) + (unsigned)hh) ^ rswz);
@@ -297,7 +412,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             bufn = bufn == NST - 1 ? 0 : bufn + 1;
         }
         __syncthreads();                             // every wave is done with the ring before it becomes the staging area
-        if (!(dbg & 8)) split_store_tile<EPI, OUT_SPLIT, WN>(g, smem, acc, m0, n0, M, wave, lane);
+        if (!(dbg & 8)) {
+            if constexpr (Cfg::MF == 16) split_store_tile16<EPI, OUT_SPLIT, WN>(g, smem, acc16, m0, n0, M, wave, lane);
+            else split_store_tile<EPI, OUT_SPLIT, WN>(g, smem, acc, m0, n0, M, wave, lane);
+        }
         __syncthreads();
     }
     if (DIAG && g.clk_probe && threadIdx.x == 0) {      // diagnostic: shader clock = d(memtime) / d(memrealtime) * 100 MHz
@@ -322,10 +440,24 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
     hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
 }
 
-// CfgB is the default for every GEMM (measured end to end: 5378 vs 5283 docs/s with CfgA for the GELU GEMM);
-// MMEE_SPLIT_CFG=A forces CfgA (A/B measurements).
+// CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283);
+// MMEE_SPLIT_CFG=A / B force the other configurations (A/B measurements).
 void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
-    static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : 0) : 0; }();
+    static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : e[0] == 'C' ? 3 : 0) : 0; }();
+    if ((forced == 3 || forced == 0) && !a.dbg_noload) {      // default: CfgC
+        if (a.out_split) {
+            if (epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true>(a, max_m, num_cus, s);
+            else launch_split_one<CfgC, EPI_BIAS, true>(a, max_m, num_cus, s);
+            return;
+        }
+        switch (epi) {
+            case EPI_BIAS: launch_split_one<CfgC, EPI_BIAS, false>(a, max_m, num_cus, s); break;
+            case EPI_GELU: launch_split_one<CfgC, EPI_GELU, false>(a, max_m, num_cus, s); break;
+            case EPI_RESID: launch_split_one<CfgC, EPI_RESID, false>(a, max_m, num_cus, s); break;
+            default: launch_split_one<CfgC, EPI_TANH, false>(a, max_m, num_cus, s); break;
+        }
+        return;
+    }
     const bool use_a = forced == 1;
     if (a.dbg_noload) {      // timing diagnostics: only the two shapes the probes use
         if (a.out_split) launch_split_one<CfgA, EPI_GELU, true, true>(a, max_m, num_cus, s);
