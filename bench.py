@@ -291,7 +291,7 @@ def main():
         fl2 = eng.flops()
         if world == 1 and not a.no_traffic:
             # kernel-name fragments of the FFN-up launches as rocprofv3 prints them
-            ksub = "SplitCfg<128, 256, 64, 3, 2, 4, 2>, 1, true" if split else "gemm_f32_dma_kernel<1, 0"
+            ksub = "16>, 1, true, false>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output
             tb, detail = measure_hbm_traffic(thr, B, ksub, eng.precision)
             line["roofline"]["traffic"] = tb
             line["roofline"]["traffic_detail"] = detail
