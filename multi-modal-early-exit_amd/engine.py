@@ -47,7 +47,7 @@ def _require_torch_cuda(device=None):
 class EarlyExitEngine:
     """One handle on one GPU.  Not thread-safe (same as the reference's one-model-per-process use)."""
 
-    def __init__(self, cfg: ModelConfig, max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32",
+    def __init__(self, cfg: ModelConfig, max_docs: int = 64, max_text_len: int = 512, precision: str = "auto",
                  device=None):
         self.lib = capi.load()
         self.device = _require_torch_cuda(device)
@@ -146,7 +146,7 @@ class EarlyExitEngine:
         self._finalized = True
 
     @classmethod
-    def from_pretrained(cls, path: str, max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32",
+    def from_pretrained(cls, path: str, max_docs: int = 64, max_text_len: int = 512, precision: str = "auto",
                         device=None, ee_config: Optional[dict] = None) -> "EarlyExitEngine":
         """Load a local HF-format checkpoint directory (config.json with ``EE_config`` + safetensors / .bin), the
         counterpart of ``LayoutLMv3EEForSequenceClassification.from_pretrained`` at EE/configs.py:404-411."""

@@ -62,7 +62,7 @@ class LayoutLMv3EEForSequenceClassification:
     """Drop-in for the reference class of the same name (inference only)."""
 
     def __init__(self, config: Union[ModelConfig, Mapping[str, Any]], weights: Optional[Mapping[str, Any]] = None,
-                 max_docs: int = 64, max_text_len: int = 512, precision: str = "fp32", device=None):
+                 max_docs: int = 64, max_text_len: int = 512, precision: str = "auto", device=None):
         if not isinstance(config, ModelConfig):
             config = ModelConfig.from_hf_dict(dict(config))
         self.model_config = config

@@ -190,3 +190,33 @@ def test_split_gemm_kernel_against_float64(pkg, M, N, K, epi, out_split, gather)
     err = float((got - ref).abs().max())
     err32 = float((f32.double() - ref).abs().max())
     assert err <= max(2.0 * err32, 1e-6), (err, err32)
+
+
+@pytest.mark.parametrize("strategy", ["ramp", "gate"])
+def test_small_split_precision_every_exit_kind_vs_oracle(pkg, oracle, strategy):
+    """Split-precision GEMM / attention kernels at the smallest shape they accept (hidden 256), every exit kind
+    (embedding-level means + encoder layers, ramp and gate), dump-all and early-exit mode, against the live numpy oracle."""
+    ee = dict(exits=["vision_avg", "text_avg", "text_visual_concat", 1, 2, 3], encoder_layer_strategy=strategy)
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                               coordinate_size=48, shape_size=32)
+    W = pkg.synth.make_weights(cfg, seed=21)
+    docs = pkg.synth.make_documents(cfg, 7, seed=5, text_len=40, min_words=2)
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], strategy=strategy, return_hidden_cls=True)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40, precision="split")
+    assert eng.precision == "split"
+    eng.load_weights(W)
+    out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True, want_all=True,
+                      want_hidden_cls=True, validate=True)
+    np.testing.assert_allclose(_np(out.hidden_cls), ref["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(_np(out.all_logits), ref["logits_store"], rtol=0, atol=LOGIT_TOL)
+    conf = oracle.softmax64(ref["logits_store"]).max(-1)
+    s = np.sort(conf.ravel())
+    k = int(np.argmax(np.diff(s)[len(s) // 4: 3 * len(s) // 4])) + len(s) // 4     # widest gap in the middle half
+    thr = 0.5 * (s[k] + s[k + 1])
+    assert np.abs(conf - thr).min() > 1e-5
+    ex, pred, cf = oracle.policy_scan(ref["logits_store"], thr)
+    for dense in (False, True):
+        o2 = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], thresholds=thr, dense_rows=dense)
+        assert np.array_equal(_np(o2.exit_layer), ex)
+        np.testing.assert_allclose(_np(o2.logits), pred, rtol=0, atol=LOGIT_TOL)
+    eng.close()
