@@ -302,8 +302,8 @@ def main():
         line["gemm_class_tflops"] = fl2["gemm"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
         line["attention_tflops"] = fl2["attention"] / (prof["attention"]["ms"] * 1e-3) / 1e12 if prof["attention"]["ms"] else None
 
-    if rank == 0 and a.cpu_docs != 0:
-        # ---- CPU baseline: the oracle = the reference's semantics (every layer, every exit, simulated policy), B=1 ---
+    if rank == 0 and world == 1 and a.cpu_docs != 0:
+        # ---- CPU baseline (N = 1 runs only): the oracle = the reference's semantics (every layer, every exit, simulated policy), B=1 ---
         oracle = importlib.import_module("oracle.ee_oracle")
         otorch = importlib.import_module("oracle.ee_oracle_torch")
         cores = min(16, os.cpu_count() or 1)        # the box's CPU share for one GPU
