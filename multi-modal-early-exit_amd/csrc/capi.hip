@@ -266,6 +266,12 @@ int ee_create(const ee_config* c, ee_handle** out) {
     if (c->precision == MMEE_PREC_F32_SPLIT &&
         !(mmee::gemm_split_supports(3 * H, H) && mmee::gemm_split_supports(H, H) && mmee::gemm_split_supports(I, H) && mmee::gemm_split_supports(H, I)))
         return fail(nullptr, "MMEE_PREC_F32_SPLIT needs hidden_size and intermediate_size to be multiples of 256 (got %d, %d)", H, I);
+    {   // the split GEMM addresses a gathered A row by a 32-bit byte offset from the tile's first source row
+        const double x_bytes = (double)c->max_docs * (double)(c->max_text_len + (c->input_size / c->patch_size) * (c->input_size / c->patch_size) + 1) * H * 4.0;
+        if (c->precision == MMEE_PREC_F32_SPLIT && x_bytes >= 4294967296.0)
+            return fail(nullptr, "MMEE_PREC_F32_SPLIT: max_docs * rows per document * hidden_size * 4 must stay below 4 GiB (got %.2f GiB); "
+                                 "use a smaller max_docs per handle", x_bytes / 1073741824.0);
+    }
     if (c->exit_head_num_layers != 1 && c->exit_head_num_layers != 2) return fail(nullptr, "exit_head_num_layers must be 1 or 2");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)

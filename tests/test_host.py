@@ -126,3 +126,40 @@ def test_model_output_container(pkg):
     o = pkg.EESequenceClassifierOutput(logits=1, loss=None, exit_states=(2,), gated_logits=())
     assert o.logits == 1 and o["logits"] == 1 and o[0] == 1 and o.loss is None and o.exit_states == (2,)
     assert list(o.keys()) == ["logits", "exit_states", "gated_logits"]
+
+
+def _base_c_config(pkg, **over):
+    c = pkg.capi.EEConfig()
+    c.abi_version = pkg.capi.ABI_VERSION
+    cfg = pkg.ModelConfig.base()
+    for f in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size", "vocab_size",
+              "max_position_embeddings", "type_vocab_size", "pad_token_id", "max_2d_position_embeddings", "coordinate_size",
+              "shape_size", "rel_pos_bins", "max_rel_pos", "rel_2d_pos_bins", "max_rel_2d_pos", "input_size", "patch_size",
+              "num_channels", "num_labels"):
+        setattr(c, f, int(getattr(cfg, f)))
+    c.layer_norm_eps = 1e-5
+    c.n_encoder_exits = 1
+    c.encoder_exit_layers[0] = 6
+    c.exit_head_num_layers = 2
+    c.max_docs, c.max_text_len, c.precision = 8, 512, 0
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+@pytest.mark.parametrize("over,needle", [
+    (dict(precision=1), "not built"),                                   # plain bf16 is rejected, not silently downgraded
+    (dict(precision=2, hidden_size=128, num_attention_heads=2, intermediate_size=256, coordinate_size=24, shape_size=16),
+     "multiples of 256"),                                               # split precision needs 256-multiples
+    (dict(precision=2, max_docs=4096), "4 GiB"),                        # 32-bit gather offsets of the split GEMM
+    (dict(num_labels=65), "num_labels"),
+    (dict(abi_version=1), "abi"),
+])
+def test_create_rejects_bad_configs_with_a_message(pkg, over, needle):
+    """ee_create validates the configuration before it touches the GPU: same behaviour on a box without one."""
+    import ctypes as C
+    lib = pkg.capi.load()
+    h = C.c_void_p()
+    rc = lib.ee_create(C.byref(_base_c_config(pkg, **over)), C.byref(h))
+    assert rc != 0 and not h.value
+    assert needle.lower() in pkg.capi.last_error(None).lower(), pkg.capi.last_error(None)
