@@ -220,3 +220,54 @@ def test_small_split_precision_every_exit_kind_vs_oracle(pkg, oracle, strategy):
         assert np.array_equal(_np(o2.exit_layer), ex)
         np.testing.assert_allclose(_np(o2.logits), pred, rtol=0, atol=LOGIT_TOL)
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["split", "fp32"])
+def test_bench_size_early_exit_properties(pkg, oracle, precision):
+    """BASELINE configs[1] shape (base, exits 2/4/6/8/10 + final, T = 512, ragged documents) at a size no CPU oracle
+    finishes in seconds — checked through properties that do not depend on the size:
+      * a document's early-exit result is BIT-identical to its dump-all result at the exit the policy picks (rows are
+        independent in every kernel, so dropping the other documents must not change a single bit);
+      * permuting the batch permutes the outputs bit for bit (work queues, compaction and tiling are order-free);
+      * the stage populations are the survivors of the exits, and every document leaves exactly once."""
+    import torch
+    ee = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.base(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=1234, head_gain=6.0)          # bench.py's gain: confidences spread over (0.2, 1)
+    B = 160
+    docs = pkg.synth.make_documents(cfg, B, seed=99, text_len=512)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=512, precision=precision)
+    eng.load_weights(W)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    full = eng.forward(*args, dump_all=True, want_all=True)
+    store = _np(full.all_logits).astype(np.float64)                     # (E+1, B, K)
+    conf = oracle.softmax64(store).max(-1)
+    thr = np.full(conf.shape[0], 2.0)
+    active = np.ones(B, dtype=bool)
+    for e in range(conf.shape[0] - 1):                                   # release ~25 % of the arrivals at every exit, in a gap
+        c = np.sort(conf[e, active])
+        k = int(0.75 * len(c))
+        lo, hi = max(1, k - 3), min(len(c) - 1, k + 3)
+        j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
+        thr[e] = 0.5 * (c[j - 1] + c[j])
+        active &= ~(conf[e] > thr[e])
+    assert np.abs(conf[:-1] - thr[:-1, None]).min() > 1e-6
+    ex_ref, pred_ref, _ = oracle.policy_scan(store, thr)
+    out = eng.forward(*args, thresholds=thr)
+    ex = _np(out.exit_layer)
+    assert np.array_equal(ex, ex_ref)
+    assert len(np.unique(ex)) >= 4                                       # the mix really exercises several stages
+    got = _np(out.logits)
+    want = _np(full.all_logits)[ex, np.arange(B)]
+    assert np.array_equal(got, want), float(np.abs(got - want).max())    # bit-identical to the dump-all rows
+    counts = eng.stage_counts()["docs"]
+    surv = [int((ex >= e).sum()) for e in range(len(counts))]
+    assert counts == surv and sum(int((ex == e).sum()) for e in range(conf.shape[0])) == B
+    # permutation invariance
+    perm = np.random.default_rng(7).permutation(B)
+    pargs = tuple(a[perm] for a in args)
+    outp = eng.forward(*pargs, thresholds=thr)
+    assert np.array_equal(_np(outp.exit_layer), ex[perm])
+    assert np.array_equal(_np(outp.logits), got[perm])
+    assert np.array_equal(_np(outp.confidence), _np(out.confidence)[perm])
+    eng.close()
