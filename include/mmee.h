@@ -50,8 +50,11 @@ enum { MMEE_ARCH_LAYOUTLMV3 = 0, MMEE_ARCH_BEIT = 1 };
 /* MMEE_PREC_F32: v_mfma_f32_32x32x2_f32 on f32 operands.  MMEE_PREC_F32_SPLIT: the four big Linear layers of every encoder
  * layer run on the f16 matrix cores with every f32 operand split into two f16 planes (hi + lo, 22 significant bits) and
  * three MFMA terms per product, f32 accumulation — measured at least as accurate as the f32 MFMA chain, same
- * 1e-4 / bit-exact parity bar; needs hidden_size and intermediate_size to be multiples of 256.  MMEE_PREC_BF16 is
- * reserved and rejected: plain bf16 cannot meet the tolerance. */
+ * 1e-4 / bit-exact parity bar; needs hidden_size and intermediate_size to be multiples of 256.  Range: the f16 planes hold
+ * 16 x LayerNorm outputs, 16 x Q/K/V, 64 x attention context, 16 x GELU outputs and 2^e x weights (e chosen per tensor at
+ * ee_finalize); values beyond +-60000 / scale (|activation| > 3750, |context| > 937) are clamped, far outside what
+ * LayoutLMv3 / DiT checkpoints produce — use MMEE_PREC_F32 for a model that exceeds it.  MMEE_PREC_BF16 is reserved and
+ * rejected: plain bf16 cannot meet the tolerance. */
 enum { MMEE_PREC_F32 = 0, MMEE_PREC_BF16 = 1, MMEE_PREC_F32_SPLIT = 2 };
 /* ee_load_tensor dtypes */
 enum { MMEE_DT_F32 = 0, MMEE_DT_F16 = 1, MMEE_DT_BF16 = 2 };
