@@ -271,3 +271,29 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
     assert np.array_equal(_np(outp.logits), got[perm])
     assert np.array_equal(_np(outp.confidence), _np(out.confidence)[perm])
     eng.close()
+
+
+def test_split_precision_edge_batches(pkg, oracle):
+    """Split-precision path at the base width on degenerate batches: one document, everybody leaving at the first exit (every
+    later stage is empty: M = 0 launches), nobody leaving, short texts; a batch larger than the handle is refused loudly."""
+    ee = dict(exits=[1, 2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=3)
+    W = pkg.synth.make_weights(cfg, seed=3, head_gain=6.0)
+    docs = pkg.synth.make_documents(cfg, 5, seed=8, text_len=24, min_words=1)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    eng = pkg.EarlyExitEngine(cfg, max_docs=5, max_text_len=24, precision="split")
+    eng.load_weights(W)
+    with pytest.raises(pkg.capi.MMEEError):
+        eng.forward(*(np.concatenate([a, a]) for a in args), dump_all=True)   # 10 documents, handle sized for 5
+    full = eng.forward(*args, dump_all=True, want_all=True)
+    store = _np(full.all_logits)
+    assert np.isfinite(store).all()
+    one = eng.forward(*(a[:1] for a in args), dump_all=True, want_all=True)
+    assert np.array_equal(_np(one.all_logits)[:, 0], store[:, 0])        # a document alone == the same document in a batch
+    everybody = eng.forward(*args, thresholds=0.0)
+    assert (_np(everybody.exit_layer) == 0).all() and np.array_equal(_np(everybody.logits), store[0])
+    nobody = eng.forward(*args, thresholds=1.5)
+    assert (_np(nobody.exit_layer) == 2).all() and np.array_equal(_np(nobody.logits), store[2])
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"])
+    np.testing.assert_allclose(store, ref["logits_store"], rtol=0, atol=LOGIT_TOL)
+    eng.close()
