@@ -297,3 +297,39 @@ def test_split_precision_edge_batches(pkg, oracle):
     ref = oracle.forward_all(cfg, W, docs, ee["exits"])
     np.testing.assert_allclose(store, ref["logits_store"], rtol=0, atol=LOGIT_TOL)
     eng.close()
+
+
+def test_baseline_config1_64_documents_threshold_sweep(pkg, oracle):
+    """BASELINE configs[0], the reference's own CPU-runnable case: LayoutLMv3-base, the repo-default exits
+    ["text_visual_concat", 6] (EE/configs.py:52) + final, ramp, 64 documents, a sweep of global thresholds that includes the
+    repo default 0.9 (EE/configs.py:51).  The CPU side is the torch-CPU restatement of the reference path (B = 1 per forward,
+    full depth, policy simulated afterwards, as the reference evaluates); the GPU side really exits."""
+    import importlib
+    import torch
+    otorch = importlib.import_module("oracle.ee_oracle_torch")
+    ee = dict(exits=["text_visual_concat", 6], encoder_layer_strategy="ramp", global_threshold=0.9)
+    cfg = pkg.ModelConfig.base(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=51, head_gain=6.0)
+    N = 64
+    docs = pkg.synth.make_documents(cfg, N, seed=52, text_len=512)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    tor = otorch.TorchOracle(cfg, W)
+    store = np.concatenate([tor.forward_all({k: v[i:i + 1] for k, v in docs.items()}, ee["exits"])["logits_store"] for i in range(N)], axis=1)
+    conf = oracle.softmax64(store).max(-1)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=N, max_text_len=512)         # precision "auto" -> split at this shape
+    assert eng.precision == "split"
+    eng.load_weights(W)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    full = eng.forward(*args, dump_all=True, want_all=True)
+    np.testing.assert_allclose(_np(full.all_logits), store, rtol=0, atol=LOGIT_TOL)
+    checked = 0
+    for thr in (0.0, 0.3, 0.5, 0.7, 0.9, 0.99, 1.0 + 1e-6):
+        if 0.0 < thr < 1.0 and np.abs(conf[:-1] - thr).min() < 2e-5:    # ill-posed: a confidence sits on the threshold
+            continue
+        ex, pred, _ = oracle.policy_scan(store, thr)
+        out = eng.forward(*args, thresholds=thr)
+        assert np.array_equal(_np(out.exit_layer), ex), thr
+        np.testing.assert_allclose(_np(out.logits), pred, rtol=0, atol=LOGIT_TOL)
+        checked += 1
+    assert checked >= 5
+    eng.close()
