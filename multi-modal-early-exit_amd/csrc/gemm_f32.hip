@@ -1,6 +1,7 @@
 // fp32 GEMM on the CDNA4 matrix cores: C[M,N] = A[M,K] * W[N,K]^T (+ bias, + fused epilogue).
 //
-// Replaces every nn.Linear / Conv2d of the encoder path in parity mode:
+// Replaces every nn.Linear / Conv2d of the encoder path (precision "fp32"; with the default split precision only the patch
+// embedding and the exit heads):
 //   QKV projection  HF:243-258 | attention output dense HF:299-303 | FFN up + GELU HF:485-497 | FFN down HF:508-512
 //   patch embedding Conv2d(k = s = 16) HF:71-83 (AMODE_IM2COL) | exit-head / classifier dense + tanh
 //   (EE/models/LayoutLMv3.py:86-93, HF:799-823) on gathered CLS rows.
@@ -14,7 +15,11 @@
 //   * K is permuted consistently for both operands: lane half h of MFMA step c in k-group g consumes
 //     k = 8g + 4h + c, so one ds_read_b128 per operand feeds four MFMAs.
 //   * LDS rows padded to 36 floats: the 16 lanes of a ds_read_b128 group start on 16 distinct 4-bank slots.
-//   * register-staged double buffering (global_load -> VGPR during compute, ds_write after), one barrier per stage.
+//   * two kernels with the same tiling and epilogue: gemm_f32_dma_kernel (default; global_load_lds straight into unpadded,
+//     XOR-swizzled LDS rows, fragment double buffering with counted lgkmcnt waits, the stage barrier placed between k-groups 2
+//     and 3 of the previous stage) and gemm_f32_kernel (register-staged double buffering into padded rows: global_load ->
+//     VGPR during compute, ds_write after; MMEE_GEMM_DMA=0 selects it).  The AMODE_IM2COL patch-embedding GEMM, the exit
+//     heads and precision "fp32" run here; the big layer GEMMs of the default precision run in gemm_split.hip.
 //   * persistent grid-stride over tiles; M is read from device memory (rows of the still-active documents), so the
 //     host never synchronises to size a launch after an exit stage.
 //   * optional row gather on A and on the residual: the stream compaction after an exit is fused into the next
