@@ -355,7 +355,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
         for (int kt = 0; kt < nk; ++kt) {
             // my pieces of stage kt have landed (NST == 3: the pieces of stage kt + 1 may still be in flight), then the
             // barrier: everyone's have, and everyone has left stage kt - 1, whose slot the next issue overwrites
-            if (dbg & 2) {                           // diagnostic: no barrier (results wrong)
+            if ((dbg & 6) == 6) {                    // diagnostic: neither the DMA wait nor the barrier
+            } else if (dbg & 2) {                    // diagnostic: no barrier (results wrong)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else if (dbg & 4) {                    // diagnostic: no DMA wait
                 asm volatile("s_barrier" ::: "memory");

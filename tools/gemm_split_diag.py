@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gemm_split_probe import run
 M = 512 * 462
-for bits, name in ((256, "full (diagnostic build)"), (16, "no in-loop DMA"), (32, "no barrier"), (64, "no DMA wait"), (128, "no epilogue"), (16 | 128, "no DMA, no epilogue"),
+for bits, name in ((256, "full (diagnostic build)"), (16, "no in-loop DMA"), (32, "no barrier"), (64, "no DMA wait"), (32 | 64, "no DMA wait, no barrier"), (128, "no epilogue"), (16 | 128, "no DMA, no epilogue"),
                    (16 | 32 | 128, "MFMA + LDS reads only")):
     print(name)
     run(M, 3072, 768, epi=1 | bits, out_split=1, iters=4)
