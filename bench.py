@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py — docs/sec (+ mean exit layer) of the MI355X early-exit document-classification path.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank / GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Started bare (`python bench.py --gpus 8`), this process launches the ranks itself as a
+child `python -m torch.distributed.run --nproc-per-node N bench.py ...` before anything touches the GPU and passes the
+child's JSON line and exit code through; started by a launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks,
+and --gpus must equal WORLD_SIZE.
 
 Workload (BASELINE.json configs[1]): LayoutLMv3-base, exit head every 2 layers (2,4,6,8,10) + final classifier, ramp
 policy (max-confidence thresholds, strict '>'), synthetic RVL-CDIP-shaped documents (512 text tokens padded + 197
@@ -54,7 +59,54 @@ def parse():
                     "rocprofv3 runs so that every forward in the process is an identical step)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes (HBM traffic)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--stream-docs", type=int, default=40000,
+                    help="N = 1 only: after the resident-batch measurement, push this many DISTINCT raw documents (uint8 pages + ragged "
+                         "token ids) through feed.DeviceFeeder -> early_exit and report feed_inclusive_docs_per_sec (0 = skip)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the launch only: every rank joins a gloo group, reports its RANK / WORLD_SIZE and exits "
+                         "without touching the GPU (CPU test of the --gpus N path)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no rank environment: start N ranks (one per GPU) as a CHILD
+    `python -m torch.distributed.run` and pass its output and exit code through.  This process never imports torch and
+    never touches the GPU (a process that has initialised HIP must not exec / be replaced, and the children need the
+    devices to themselves)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(a, world, rank):
+    """Launch rehearsal: no GPU call.  Rank 0 prints which ranks joined."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        seen = torch.zeros(world, dtype=torch.int64)
+        mine = torch.tensor([rank], dtype=torch.int64)
+        dist.all_gather_into_tensor(seen, mine)
+        ranks = seen.tolist()
+        dist.destroy_process_group()
+    else:
+        ranks = [0]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "rccl_ranks": world, "ranks_seen": ranks,
+                          "world_size_env": os.environ.get("WORLD_SIZE"), "gpus_arg": a.gpus}))
 
 
 def calibrate_thresholds(conf, release):
@@ -95,6 +147,7 @@ def measure_hbm_traffic(thr, batch, kernel_substr, precision, timeout=240):
         d = tempfile.mkdtemp(prefix="mmee_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
                os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic",
+               "--stream-docs", "0",
                "--batch", str(batch), "--precision", precision, "--thresholds", ",".join(repr(float(t)) for t in thr[:-1])]
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
@@ -120,15 +173,27 @@ def measure_hbm_traffic(thr, batch, kernel_substr, precision, timeout=240):
 
 def main():
     a = parse()
-    import torch
-    import torch.distributed as dist
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:                       # parent of the ranks: nothing below this line runs in it
+            sys.exit(launch_ranks(a))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+                 f"pass --gpus {os.environ['WORLD_SIZE']} (or run `python bench.py --gpus N` and let it launch the ranks)")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.dry_launch:
+        return dry_launch(a, world, rank)
+    import torch
+    import torch.distributed as dist
     # one process per GPU over RCCL ("nccl"); MMEE_DIST_BACKEND=gloo lets two ranks share one GPU to rehearse the flow on a
     # one-GPU box (collectives then travel through host memory)
     backend = os.environ.get("MMEE_DIST_BACKEND", "nccl")
     ndev = max(1, torch.cuda.device_count())
+    if backend == "nccl" and world > ndev:
+        sys.exit(f"bench.py: {world} RCCL ranks but only {ndev} GPU(s) visible (MMEE_DIST_BACKEND=gloo rehearses on fewer)")
     local_dev = local % ndev if backend != "nccl" else local
     dev = torch.device(f"cuda:{local_dev}")
     torch.cuda.set_device(dev)
@@ -137,27 +202,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective payloads live
-
-    def bcast(t):
-        x = t.to(cdev)
-        dist.broadcast(x, 0)
-        return x.to(t.device)
-
-    def allgather_rows(t):
-        x = t.to(cdev).contiguous()
-        outs = [torch.empty_like(x) for _ in range(world)] if backend != "nccl" else None
-        if backend == "nccl":
-            g = torch.empty((world * x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
-            dist.all_gather_into_tensor(g, x)
-            return g
-        dist.all_gather(outs, x)
-        return torch.cat(outs, 0).to(t.device)
-
-    def allmax(v):
-        x = torch.tensor([v], dtype=torch.float64, device=cdev)
-        dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        return float(x.item())
 
     pkg = importlib.import_module("multi-modal-early-exit_amd")
 
@@ -197,10 +241,22 @@ def main():
         conf = out.all_crit.cpu().numpy().astype(np.float64)
         thr = calibrate_thresholds(conf, a.release)
     if world > 1:                       # every rank uses rank 0's thresholds
-        thr = bcast(torch.from_numpy(thr).to(dev)).cpu().numpy()
+        thr = pkg.dist.broadcast_array(thr, 0, device=dev)
 
     def step():
         return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows, temperatures=temps)
+
+    def run_local(idx):
+        # this rank's shard of the job's documents (global document g = rank + world * i, i = step * B + position): K steps of
+        # the hot path over the resident batch, one (logits | exit_layer | confidence) row per document
+        rows = []
+        for _ in range(a.steps):
+            o = step()
+            rows.append(pkg.dist.pack_results(o.logits, o.exit_layer, o.confidence))
+        run_local.last = o
+        r = torch.cat(rows, dim=0)
+        assert r.shape[0] == len(idx)
+        return r
 
     for _ in range(a.warmup):
         out = step()
@@ -209,22 +265,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    results = []
-    for _ in range(a.steps):
-        out = step()
-        results.append(torch.cat([out.logits, out.exit_layer.float().unsqueeze(1), out.confidence.unsqueeze(1)], dim=1))
-    local_res = torch.cat(results, dim=0)
-    if world > 1:                       # the one collective of the path: per-document (logits, exit, confidence)
-        gathered = allgather_rows(local_res)
-    else:
-        gathered = local_res
+
+    # no data-path collective; the one all-gather of the per-document results closes the timed region (RCCL over xGMI)
+    gathered = pkg.dist.run_sharded(run_local, world * B * a.steps, rank, world)
+    out = run_local.last
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        dt = allmax(dt)
+        dt = pkg.dist.max_over_ranks(dt, device=dev)
 
     n_docs = gathered.shape[0]
     exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
@@ -233,7 +284,9 @@ def main():
     fl = eng.flops()
 
     line = {
-        "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world, "steps": a.steps,
+        "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world, "rccl_ranks": world,
+        "collective_backend": ("none (single rank)" if world == 1 else "RCCL all_gather_into_tensor" if backend == "nccl" else backend),
+        "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if eng.precision in ("fp32", "f32") else "f32 (operands split into 2 x f16, 3 f16 MFMA terms per MAC, f32 accumulate)",
@@ -301,6 +354,30 @@ def main():
                 line["roofline"]["algorithmic_hbm_bytes_per_launch"] = alg
         line["gemm_class_tflops"] = fl2["gemm"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
         line["attention_tflops"] = fl2["attention"] / (prof["attention"]["ms"] * 1e-3) / 1e12 if prof["attention"]["ms"] else None
+
+    if rank == 0 and world == 1 and a.stream_docs > 0 and not beit:
+        # ---- streaming run: every document distinct, host packing + PCIe + device preprocessing inside the clock (the reference's
+        # loop being replaced: EE/utils.py:93-98, 169-173).  The headline `value` stays the resident-batch rate. ---------------------
+        stream = pkg.synth.RawDocumentStream(cfg, a.stream_docs, seed=a.seed + 77, text_len=T)
+        feeder = pkg.feed.DeviceFeeder(stream, batch_size=B, size=cfg.input_size, max_length=T, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        srows = []
+        for batch in feeder:
+            o = eng.forward(batch["input_ids"], batch["attention_mask"], batch["bbox"], batch["pixel_values"], thresholds=thr,
+                            dense_rows=a.dense_rows, temperatures=temps)
+            srows.append(pkg.dist.pack_results(o.logits, o.exit_layer, o.confidence))
+        srows = torch.cat(srows, dim=0)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - t1
+        sex = srows[:, cfg.num_labels].cpu().numpy().astype(np.int64)
+        line["feed_inclusive_docs_per_sec"] = len(stream) / sdt
+        line["feed_inclusive"] = {"docs": len(stream), "distinct_documents": True, "seconds": sdt,
+                                  "h2d_bytes_per_doc": feeder.bytes_h2d / max(1, len(stream)),
+                                  "mean_exit_layer": float(layer_of_exit[sex].mean()),
+                                  "what": "RawDocumentStream (1000x762 uint8 pages, ragged ids/boxes) -> DeviceFeeder (pinned double "
+                                          "buffer, one async H2D copy per batch, resize/normalise/pad on a side stream) -> ee_forward; "
+                                          "host packing, PCIe and preprocessing are inside the clock, page synthesis is not"}
 
     if rank == 0 and world == 1 and a.cpu_docs != 0:
         # ---- CPU baseline (N = 1 runs only): the oracle = the reference's semantics (every layer, every exit, simulated policy), B=1 ---

@@ -81,6 +81,11 @@ struct ee_handle {
     std::vector<ProfRec> prof_recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     size_t prof_used = 0;
+    // the workspace is shared by consecutive forwards: a forward enqueued on another stream than the previous one first
+    // waits for it (one handle = one forward in flight)
+    hipEvent_t fwd_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_fwd = false;
     // bookkeeping of the last forward
     int last_B = 0, last_T = 0, last_stages = 0;
     std::vector<int> layer_stage;
@@ -450,6 +455,7 @@ int ee_destroy(ee_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
     for (void* q : h->allocs) (void)hipFree(q);
     delete h;
     return 0;
@@ -632,6 +638,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     auto S_x_src = [&](int st) { return h->x_src + st * sstride; };
     auto S_meta_src = [&](int st) { return h->meta_src + st * sstride; };
 
+    if (!h->fwd_done) HIP_OK(h, hipEventCreateWithFlags(&h->fwd_done, hipEventDisableTiming));
+    if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
     h->next_queue_head = 0;
@@ -662,6 +670,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     pa.attention_mask = (const long long*)attention_mask;
     pa.bbox = (const long long*)bbox;
     pa.position_ids = (const long long*)position_ids;
+    pa.token_type_ids = (const long long*)token_type_ids; pa.type_vocab = c.type_vocab_size;
     pa.B = B; pa.T = T; pa.Pv = Pv; pa.G = G;
     pa.pad_id = c.pad_token_id; pa.vocab = c.vocab_size; pa.max_2d = c.max_2d_position_embeddings; pa.max_pos = c.max_position_embeddings;
     pa.dense_rows = (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0;
@@ -675,6 +684,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     ea.input_ids = pa.input_ids; ea.token_type_ids = (const long long*)token_type_ids; ea.bbox = pa.bbox;
     ea.emb_pos = h->emb_pos; ea.text_dst = h->text_dst; ea.ntext = h->ntext; ea.doc_off = S_doc_off(0);
     ea.B = B; ea.T = T; ea.Pv = Pv; ea.H = H; ea.cs = c.coordinate_size; ea.ss = c.shape_size; ea.max_2d = c.max_2d_position_embeddings;
+    ea.vocab = c.vocab_size; ea.type_vocab = c.type_vocab_size;
     ea.word = h->word; ea.type = h->type; ea.pos = h->pos; ea.xtab = h->xtab; ea.ytab = h->ytab; ea.htab = h->htab; ea.wtab = h->wtab;
     ea.ln1_g = h->emb_g; ea.ln1_b = h->emb_b; ea.eps1 = c.layer_norm_eps;
     ea.ln2_g = h->ln_g; ea.ln2_b = h->ln_b; ea.eps2 = c.layer_norm_eps;
@@ -875,6 +885,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         run_exit(nullptr, h->X, H, x_phys, true);
     }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
+    HIP_OK(h, hipEventRecord(h->fwd_done, s));
+    h->last_stream = s; h->has_fwd = true;
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -891,7 +903,7 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
         if (docs_out) docs_out[i] = sc[h->exit_stage[i]].n_docs;
         if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
     }
-    if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id)", err);
+    if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id, 8 = token_type id)", err);
     return 0;
 }
 

@@ -9,8 +9,9 @@ struct PrepArgs {
     const long long* attention_mask; // (B,T) or null
     const long long* bbox;           // (B,T,4)
     const long long* position_ids;   // (B,T) or null
+    const long long* token_type_ids; // (B,T) or null (range check only; the embedding kernel reads them)
     int B, T, Pv, G;
-    int pad_id, vocab, max_2d, max_pos;
+    int pad_id, vocab, max_2d, max_pos, type_vocab;
     int dense_rows;
     // outputs
     int* text_dst;                   // (B,T) row index inside the document, -1 = dropped pad row
@@ -21,7 +22,7 @@ struct PrepArgs {
     int* doc_orig;                   // (B)
     RowMeta* meta;
     StageCounts* counts;
-    int* err_flag;                   // bit0 token id out of range, bit1 bbox out of range, bit2 position id out of range
+    int* err_flag;                   // bit0 token id, bit1 bbox, bit2 position id, bit3 token_type id out of range
 };
 
 struct EmbedArgs {
@@ -32,7 +33,7 @@ struct EmbedArgs {
     const int* text_dst;
     const int* ntext;
     const int* doc_off;
-    int B, T, Pv, H, cs, ss, max_2d;
+    int B, T, Pv, H, cs, ss, max_2d, vocab, type_vocab;
     const float *word, *type, *pos, *xtab, *ytab, *htab, *wtab;
     const float *ln1_g, *ln1_b;      // text: embeddings.LayerNorm; visual: layoutlmv3.norm
     float eps1;

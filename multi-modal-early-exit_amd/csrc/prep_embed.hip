@@ -31,6 +31,10 @@ __global__ __launch_bounds__(256) void doc_prep_kernel(PrepArgs a) {
             kept_cnt += (a.dense_rows || valid || j == 0) ? 1 : 0;
             np_cnt += (id != a.pad_id) ? 1 : 0;
             bad |= (id < 0 || id >= a.vocab) ? 1 : 0;
+            if (a.token_type_ids) {
+                const long long tt = a.token_type_ids[(size_t)b * T + j];
+                bad |= (tt < 0 || tt >= a.type_vocab) ? 8 : 0;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const long long v = a.bbox[((size_t)b * T + j) * 4 + c];
@@ -196,8 +200,12 @@ __global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
         const int j = ch * 32 + wave * 8 + t;
         if (j >= T) break;                                    // wave-uniform
         const size_t tok = (size_t)b * T + j;
-        const long long id = a.input_ids[tok];
-        const int tt = a.token_type_ids ? (int)a.token_type_ids[tok] : 0;
+        // out-of-range ids are reported through err_flag by doc_prep_kernel; here they are clamped so that the table
+        // lookups stay inside the tables (as bbox and position ids are)
+        long long id = a.input_ids[tok];
+        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
+        long long ttl = a.token_type_ids ? a.token_type_ids[tok] : 0;
+        const int tt = (int)(ttl < 0 ? 0 : (ttl >= a.type_vocab ? a.type_vocab - 1 : ttl));
         const int pid = a.emb_pos[tok];
         int bb[4];
 #pragma unroll

@@ -35,6 +35,13 @@ def unpack_results(rows):
     return rows[:, :K], rows[:, K].round().to(torch.int32), rows[:, K + 1]
 
 
+def _collective_device(t, group=None):
+    """Where a collective's payload must live: RCCL ("nccl") moves device memory over xGMI; "gloo" (CPU tests, or two ranks
+    rehearsing the flow on one GPU) moves host memory."""
+    import torch.distributed as dist
+    return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def all_gather_results(local_rows, n_docs: int, rank: int, world: int, group=None):
     """One all-gather of every rank's ``(n_local, C)`` rows; returns ``(n_docs, C)`` in original document order.
     Shards may differ by one row: each rank pads to the largest shard so a single fixed-size collective suffices."""
@@ -45,17 +52,18 @@ def all_gather_results(local_rows, n_docs: int, rank: int, world: int, group=Non
     C = local_rows.shape[1]
     if local_rows.shape[0] != shard_size(n_docs, rank, world):
         raise ValueError(f"rank {rank} holds {local_rows.shape[0]} rows, expected {shard_size(n_docs, rank, world)}")
-    buf = torch.zeros((n_max, C), dtype=local_rows.dtype, device=local_rows.device)
-    buf[:local_rows.shape[0]] = local_rows
-    out = torch.empty((world * n_max, C), dtype=local_rows.dtype, device=local_rows.device)
+    cdev = _collective_device(local_rows, group)
+    buf = torch.zeros((n_max, C), dtype=local_rows.dtype, device=cdev)
+    buf[:local_rows.shape[0]] = local_rows.to(cdev)
+    out = torch.empty((world * n_max, C), dtype=local_rows.dtype, device=cdev)
     dist.all_gather_into_tensor(out, buf, group=group)
     # rank r, local row i  <->  document r + i * world
-    res = torch.empty((n_docs, C), dtype=local_rows.dtype, device=local_rows.device)
+    res = torch.empty((n_docs, C), dtype=local_rows.dtype, device=cdev)
     for r in range(world):
         n_r = shard_size(n_docs, r, world)
         if n_r:
             res[r::world][:n_r] = out[r * n_max:r * n_max + n_r]
-    return res
+    return res.to(local_rows.device)
 
 
 def run_sharded(run_local: Callable, n_docs: int, rank: int, world: int, group=None):
@@ -63,3 +71,23 @@ def run_sharded(run_local: Callable, n_docs: int, rank: int, world: int, group=N
     idx = shard_indices(n_docs, rank, world)
     rows = run_local(idx)
     return all_gather_results(rows, n_docs, rank, world, group)
+
+
+def broadcast_array(a: np.ndarray, src: int = 0, device=None, group=None) -> np.ndarray:
+    """Every rank gets rank ``src``'s array (thresholds / temperatures are inputs of the path, EE/policy.py:12-24: every
+    shard must test its documents against the same values)."""
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    dist.broadcast(t, src, group=group)
+    return t.cpu().numpy()
+
+
+def max_over_ranks(v: float, device=None, group=None) -> float:
+    import torch.distributed as dist
+    t = torch.tensor([v], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -130,9 +130,13 @@ class EarlyExitEngine:
                         t = t.float()
                     t = t.contiguous()
                     dt = {torch.float32: capi.DT_F32, torch.float16: capi.DT_F16, torch.bfloat16: capi.DT_BF16}[t.dtype]
-                    if t.is_cuda and dt != capi.DT_F32:
-                        t = t.float()
-                        dt = capi.DT_F32
+                    if t.is_cuda:
+                        if dt != capi.DT_F32:
+                            t = t.float()
+                            dt = capi.DT_F32
+                        # ee_load_tensor copies on the null stream: whatever produced ``t`` on torch's current stream (the
+                        # cast above, or the caller's own kernels) must have finished first
+                        torch.cuda.current_stream(t.device).synchronize()
                     shape = (C.c_int64 * t.dim())(*t.shape)
                     rc = self.lib.ee_load_tensor(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(), dt,
                                                  1 if t.is_cuda else 0)

@@ -193,3 +193,56 @@ def make_page_image(seed: int, h: int, w: int, channels: int = 1) -> np.ndarray:
         a[y0:y0 + int(rng.integers(1, 6)), x0:x0 + int(rng.integers(5, 120))] = int(rng.integers(0, 90))
     a = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
     return a[:, :, 0] if channels == 1 else a
+
+
+class RawDocumentStream:
+    """``n_docs`` DISTINCT raw documents for the device-side feed (feed.DeviceFeeder): what a dataset reader hands over
+    before any preprocessing — a uint8 greyscale page of RVL-CDIP size (1000 x 762), the ragged token ids ``<s> w1 .. wn </s>``
+    with one box per token (distributions of SURVEY.md section 8d), a label.  Token ids / boxes are drawn once, vectorised; a page
+    is a window of one of ``n_pages`` pre-drawn scans at a per-document offset (a view: no per-document generation cost, every
+    document still gets different pixels), so iterating costs what reading decoded pages from memory would."""
+
+    PAGE_H, PAGE_W, MARGIN = 1000, 762, 96
+
+    def __init__(self, cfg: ModelConfig, n_docs: int, seed: int = 1234, text_len: int = 512, min_words: int = 16, n_pages: int = 64):
+        rng = np.random.default_rng(seed)
+        self.n = int(n_docs)
+        T = text_len
+        nw = rng.integers(min(min_words, T - 2), T - 1, size=self.n)             # words per document, U{16 .. T-2}
+        cnt = nw + 2
+        self.off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        tot = int(self.off[-1])
+        doc = np.repeat(np.arange(self.n), cnt)
+        first = np.zeros(tot, bool); first[self.off[:-1]] = True
+        last = np.zeros(tot, bool); last[self.off[1:] - 1] = True
+        word = ~(first | last)
+        ids = rng.integers(3, cfg.vocab_size, size=tot).astype(np.int64)
+        ids[first] = 0
+        ids[last] = 2
+        x0 = rng.integers(0, 951, size=tot)
+        y0 = rng.integers(0, 951, size=tot)
+        y0 = np.sort(doc * 1024 + np.where(word, y0 + 1, np.where(first, 0, 1023))) - doc * 1024 - 1     # reading order per document
+        bw = rng.integers(5, 201, size=tot)
+        bh = rng.integers(5, 41, size=tot)
+        box = np.stack([x0, y0, np.minimum(x0 + bw, 1000), np.minimum(y0 + bh, 1000)], axis=1).astype(np.int64)
+        box[~word] = 0
+        self.ids, self.box = ids, box
+        self.labels = rng.integers(0, cfg.num_labels, size=self.n).astype(np.int64)
+        H, W, M = self.PAGE_H, self.PAGE_W, self.MARGIN
+        self.pages = [make_page_image(seed + 7919 * (i + 1), H + M, W + M, 1) for i in range(n_pages)]
+        self.page_of = rng.integers(0, n_pages, size=self.n)
+        self.dy = rng.integers(0, M, size=self.n)
+        self.dx = rng.integers(0, M, size=self.n)
+
+    def __len__(self):
+        return self.n
+
+    def sample(self, i: int):
+        a, b = int(self.off[i]), int(self.off[i + 1])
+        dy, dx = int(self.dy[i]), int(self.dx[i])
+        return {"image": self.pages[int(self.page_of[i])][dy:dy + self.PAGE_H, dx:dx + self.PAGE_W],
+                "input_ids": self.ids[a:b], "bbox": self.box[a:b], "labels": int(self.labels[i])}
+
+    def __iter__(self):
+        for i in range(self.n):
+            yield self.sample(i)

@@ -119,6 +119,18 @@ def test_input_validation_flags(pkg):
     bad[0, 1, 2] = 5000
     with pytest.raises(pkg.capi.MMEEError, match="out of range"):
         eng.forward(g["in_input_ids"], g["in_attention_mask"], bad, g["in_pixel_values"], validate=True)
+    # token ids / token_type ids far outside their tables: reported, never dereferenced (no GPU fault)
+    for wild in (-1, 2 ** 40, cfg.vocab_size):
+        ids = g["in_input_ids"].copy()
+        ids[1, 3] = wild
+        with pytest.raises(pkg.capi.MMEEError, match="out of range"):
+            eng.forward(ids, g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"], validate=True)
+    tt = np.zeros_like(g["in_input_ids"])
+    tt[0, 2] = 7
+    with pytest.raises(pkg.capi.MMEEError, match="token_type"):
+        eng.forward(g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"], token_type_ids=tt, validate=True)
+    out = eng.forward(g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"], validate=True)   # still alive
+    assert np.isfinite(out.logits.cpu().numpy()).all()
     with pytest.raises(pkg.capi.MMEEError):
         eng.forward(np.zeros((9, 48), np.int64), None, np.zeros((9, 48, 4), np.int64), np.zeros((9, 3, 64, 64), np.float32))
     W = pkg.synth.make_weights(cfg, seed=7)
@@ -245,14 +257,18 @@ def test_device_collation_and_feeder(pkg):
         assert np.array_equal(ids[i, :n].cpu().numpy(), np.asarray(s["input_ids"][:n])) and (ids[i, n:] == 1).all()
         assert am[i].sum().item() == n and (am[i, :n] == 1).all()
         assert np.array_equal(bb[i, :n].cpu().numpy(), np.asarray(s["bbox"])[:n]) and (bb[i, n:] == 0).all()
-    seen = 0
-    for batch in pkg.feed.DeviceFeeder(samples, batch_size=3, max_length=T):
-        b = batch["input_ids"].shape[0]
-        ref = pkg.feed.preprocess_images([s["image"] for s in samples[seen:seen + b]], 224)
-        assert torch.equal(batch["pixel_values"], ref) and torch.equal(batch["input_ids"], ids[seen:seen + b])
-        assert batch["labels"].tolist() == [s["labels"] for s in samples[seen:seen + b]]
-        seen += b
-    assert seen == 7
+    for bs in (3, 2):                       # 3 and 4 batches: both pinned slots are re-used
+        seen = 0
+        feeder = pkg.feed.DeviceFeeder(samples, batch_size=bs, max_length=T)
+        for batch in feeder:
+            b = batch["input_ids"].shape[0]
+            ref = pkg.feed.preprocess_images([s["image"] for s in samples[seen:seen + b]], 224)
+            assert torch.equal(batch["pixel_values"], ref) and torch.equal(batch["input_ids"], ids[seen:seen + b])
+            assert torch.equal(batch["bbox"], bb[seen:seen + b]) and torch.equal(batch["attention_mask"], am[seen:seen + b])
+            assert batch["labels"].tolist() == [s["labels"] for s in samples[seen:seen + b]]
+            seen += b
+        assert seen == 7
+        assert all(sl.host is not None and sl.host.is_pinned() for sl in feeder.slots) and feeder.bytes_h2d > 0
 
 
 def test_dit_model_wrapper(pkg):
