@@ -2,9 +2,12 @@
 loop in ``calibrate()`` (EE/eval.py:277-346) that fits one temperature per exit on validation logits and divides the test
 logits by it.
 
-``fit_temperatures`` returns what ``calibrate`` stores in ``config["calibration_metrics"]`` except ``ece``: the reference
-computes ECE with a remote metric (``evaluate.load("jordyvl/ece")``, EE/metrics.py:479-498) that cannot be fetched
-offline, so it is not restated here.
+``fit_temperatures`` returns what ``calibrate`` stores in ``config["calibration_metrics"]``: temperature, accuracy, average
+confidence and ECE per exit.  ECE — PARITY UNPINNED: the reference computes it with a remote metric
+(``evaluate.load("jordyvl/ece")``, EE/metrics.py:479-498) whose code is neither in the reference tree nor fetchable offline;
+``expected_calibration_error`` restates the metric from the arguments the reference passes (equal-mass bins,
+``n_bins = min(N - 1, 100)``, ``bin_range = [0, 1]``, upper-edge proxy, p = 1) and is pinned only by hand-computed cases in
+tests/test_host.py.  It is host-side numpy on N confidences per exit (a sort and 100 bin means), not part of the hot path.
 """
 from __future__ import annotations
 
@@ -17,9 +20,53 @@ from . import capi
 from .engine import _require_torch_cuda, torch
 
 
-def fit_temperatures(logits, labels, max_iter: int = 100, device=None) -> Dict[str, np.ndarray]:
+def _softmax64(z):
+    z = np.asarray(z, dtype=np.float64)
+    z = z - z.max(-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(-1, keepdims=True)
+
+
+def expected_calibration_error(references, predictions, n_bins: int = None, scheme: str = "equal-mass", bin_range=(0.0, 1.0),
+                               proxy: str = "upper-edge", p: int = 1) -> float:
+    """Top-label calibration error with the arguments of ``ece_logits`` (EE/metrics.py:479-498); PARITY UNPINNED (module
+    docstring).  ``predictions`` (N,K): probabilities, or logits (softmaxed when the rows do not sum to 1, as the reference
+    does).  Bins over the top-label confidence: equal-mass edges ``sorted_conf[floor(k N / n_bins)]``, k = 0..n_bins-1, plus the
+    right end of ``bin_range``; a bin is [edge_k, edge_k+1), the last one closed; empty or duplicate-edge bins carry no weight.
+    The calibrated accuracy of a bin is its ``proxy`` ("upper-edge": edge_k+1; "center": the midpoint);
+    ECE = (sum_k w_k |acc_k - proxy_k|^p)^(1/p) with w_k = the share of samples in bin k."""
+    P = np.asarray(predictions, dtype=np.float64)
+    y = np.asarray(references).reshape(-1)
+    if P.ndim != 2 or P.shape[0] != y.shape[0]:
+        raise ValueError("predictions must be (N,K) with one reference per row")
+    N = P.shape[0]
+    if not np.isclose(np.sum(P), N):                        # EE/metrics.py:480-481
+        P = _softmax64(P)
+    if n_bins is None:
+        n_bins = min(N - 1, 100)                            # EE/metrics.py:485
+    n_bins = max(1, int(n_bins))
+    conf = P.max(-1)
+    correct = (P.argmax(-1) == y).astype(np.float64)
+    if scheme == "equal-mass":
+        srt = np.sort(conf)
+        edges = np.concatenate([srt[(np.arange(n_bins) * N) // n_bins], [float(bin_range[1])]])
+    elif scheme == "equal-range":
+        edges = np.linspace(float(bin_range[0]), float(bin_range[1]), n_bins + 1)
+    else:
+        raise ValueError("scheme must be 'equal-mass' or 'equal-range'")
+    idx = np.searchsorted(edges, conf, side="right") - 1     # right-continuous bins, as numpy.digitize
+    idx = np.clip(idx, 0, n_bins - 1)                        # the right end belongs to the last bin
+    cnt = np.bincount(idx, minlength=n_bins).astype(np.float64)
+    acc = np.divide(np.bincount(idx, weights=correct, minlength=n_bins), cnt, out=np.zeros(n_bins), where=cnt > 0)
+    target = edges[1:] if proxy == "upper-edge" else 0.5 * (edges[:-1] + edges[1:])
+    w = cnt / N
+    return float(np.sum(w * np.abs(acc - target) ** p) ** (1.0 / p))
+
+
+def fit_temperatures(logits, labels, max_iter: int = 100, device=None, with_ece: bool = True) -> Dict[str, np.ndarray]:
     """``logits`` (E1,N,K) validation logits (numpy / torch, evaluated as float64), ``labels`` (N,).  Returns numpy arrays
-    ``temperature``, ``nll``, ``accuracy``, ``average_confidence`` (each (E1,)) and ``iterations``."""
+    ``temperature``, ``nll``, ``accuracy``, ``average_confidence``, ``ece`` (each (E1,); accuracy / confidence / ECE AFTER scaling,
+    as EE/eval.py:313-337 records them) and ``iterations``."""
     lib = capi.load()
     dev = _require_torch_cuda(device)
     to = lambda x, dt: (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(dev, dt).contiguous()
@@ -41,7 +88,23 @@ def fit_temperatures(logits, labels, max_iter: int = 100, device=None) -> Dict[s
                    "ee_temperature_fit")
     res = {k: v.cpu().numpy() for k, v in out.items()}
     res["iterations"] = iters.cpu().numpy()
+    if with_ece:
+        Lh, yh = L.cpu().numpy(), y.cpu().numpy()
+        res["ece"] = np.array([expected_calibration_error(yh, Lh[e] / res["temperature"][e]) for e in range(E1)])
     return res
+
+
+def calibrate(validation_logits, validation_references, test_logits, device=None):
+    """The loop of ``calibrate()`` (EE/eval.py:277-346) without its file cache: one temperature per exit fitted on the
+    validation logits, the test logits divided by it, and ``calibration_metrics`` = {ece, accuracy, temperature,
+    average_confidence} (lists, one entry per exit) — the dictionary ``Policy.accuracy_calibration_heuristic`` reads
+    (EE/policy.py:59-79).  Metrics are those of the scaled VALIDATION logits.  Returns (calibrated_test_logits, metrics)."""
+    fit = fit_temperatures(validation_logits, validation_references, device=device)
+    T = fit["temperature"]
+    cal = np.asarray(test_logits, dtype=np.float64) / T[:, None, None]
+    metrics = {"ece": [float(v) for v in fit["ece"]], "accuracy": [float(v) for v in fit["accuracy"]],
+               "temperature": [float(v) for v in T], "average_confidence": [float(v) for v in fit["average_confidence"]]}
+    return cal, metrics
 
 
 class TemperatureScaler:

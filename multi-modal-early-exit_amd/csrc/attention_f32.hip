@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
     const int my_xcd = a.item_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
     int q_try = 0;
     int item = blockIdx.x;
+    float amax = 0.f;
     for (;; item += gridDim.x) {
         int doc, head, qt;
         if (a.item_counter) {
@@ -249,8 +250,8 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { w0[c] = o0[4 * q4 + c] * inv; w1[c] = o1[4 * q4 + c] * inv; }
                     if (a.ctx_split) {                 // the attention-output GEMM reads split-f16 rows
-                        store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale);
-                        store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale);
+                        store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale, amax);
+                        store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale, amax);
                     } else {
                         *reinterpret_cast<f32x4*>(op + 8 * q4) = w0;
                         *reinterpret_cast<f32x4*>(op + 8 * q4 + 32) = w1;
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
             }
         }
     }
+    if (a.ctx_split) split_flag_overflow(amax, a.err_flag);
 }
 
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {

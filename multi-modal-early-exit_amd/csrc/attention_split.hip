@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, WGS) void attention_split_kernel(const AttnArg
     // lane 4q + p of the group supplies row key0 + q, d = d0 + 4p .. 4p + 3
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
 
+    float amax = 0.f;
     for (;; item += gridDim.x) {
         int doc, head, qt;
         if (a.item_counter) {
@@ -295,12 +296,14 @@ __global__ __launch_bounds__(256, WGS) void attention_split_kernel(const AttnArg
                     f32x4 w0, w1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { w0[c] = o0[4 * q4 + c] * inv; w1[c] = o1[4 * q4 + c] * inv; }
-                    store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale);
-                    store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale);
+                    store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale, amax);
+                    store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale, amax);
                 }
             }
         }
     }
+    if (a.ctx_split) split_flag_overflow(amax, a.err_flag);
+    if (a.ctx_split) split_flag_overflow(amax, a.err_flag);
 }
 
 void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {

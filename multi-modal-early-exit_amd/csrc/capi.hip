@@ -86,6 +86,8 @@ struct ee_handle {
     hipEvent_t fwd_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_fwd = false;
+    // err_flag of the last forward, copied to pinned host memory behind it: the next call reports it without a synchronisation
+    int* err_host = nullptr;
     // bookkeeping of the last forward
     int last_B = 0, last_T = 0, last_stages = 0;
     std::vector<int> layer_stage;
@@ -456,6 +458,7 @@ int ee_destroy(ee_handle* h) {
     (void)hipDeviceSynchronize();
     for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
+    if (h->err_host) (void)hipHostFree(h->err_host);
     for (void* q : h->allocs) (void)hipFree(q);
     delete h;
     return 0;
@@ -639,6 +642,16 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     auto S_meta_src = [&](int st) { return h->meta_src + st * sstride; };
 
     if (!h->fwd_done) HIP_OK(h, hipEventCreateWithFlags(&h->fwd_done, hipEventDisableTiming));
+    if (!h->err_host) {
+        HIP_OK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocDefault));
+        *h->err_host = 0;
+    }
+    if (h->has_fwd && hipEventQuery(h->fwd_done) == hipSuccess && *h->err_host) {
+        const int e = *h->err_host;
+        *h->err_host = 0;
+        return fail(h, "ee_forward: the PREVIOUS forward on this handle reported error flags %d (%s); its results are invalid", e,
+                    (e & mmee::kErrSplitOverflow) ? "split-precision overflow: run this checkpoint with precision \"fp32\"" : "input out of range");
+    }
     if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
@@ -717,7 +730,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
 
     const bool sp = h->split;
     if (sp && !beit)     // the first QKV projection reads split-f16 rows; later layers get them from the LayerNorm kernel
-        mmee::launch_split_rows(h->X, h->Xs, &h->counts[0].n_rows, 0, max_rows, H, mmee::kSplitScaleX, cus, s);
+        mmee::launch_split_rows(h->X, h->Xs, &h->counts[0].n_rows, 0, max_rows, H, mmee::kSplitScaleX, cus, s, h->err_flag);
     auto run_gemm = [&](const GemmArgs& g, int epi) {
         if (sp) launch_gemm_split(g, epi, max_rows, cus, s);
         else launch_gemm_f32(g, epi, AMODE_ROWS, max_rows, cus, s);
@@ -738,7 +751,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (hw.dense_w) {
             GemmArgs g{};
             g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
-            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             launch_gemm_f32(g, EPI_TANH, AMODE_ROWS, B, cus, s);
             hin = hid; hld = H; hg = nullptr;
         }
@@ -806,64 +819,64 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (beit) {
             // BeitLayer.forward (BEIT:406-444): pre-LN, layer scale.  Z = CTX buffer (LN output / attention output by turns)
             GemmArgs g{};
-            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX); }
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
             g.A = h->CTX; g.lda = H; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
             g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
-            g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
+            g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
             AttnArgs at{};
             at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
             at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
             at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
-            at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
+            at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
             { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
             g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
             g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
-            g.col_scale = w.lam1; g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+            g.col_scale = w.lam1; g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
-            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->CTX, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX); }
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->CTX, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
             g = GemmArgs{};
             g.A = h->CTX; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f;
             g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
-            g.tile_counter = next_head(); g.prio_mode = 1;
+            g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
             g = GemmArgs{};      // X = Y + lambda_2 * (h1 W2^T + b2)
             g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H; g.col_scale = w.lam2;
             g.alpha = w.f2_inv / mmee::kSplitScaleH1;
-            g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+            g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
         } else {
         GemmArgs g{};
         // QKV projection, Q pre-divided by sqrt(d) (HF:263)
         g.A = sp ? h->Xs : h->X; g.lda = H; g.row_src = rs; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
         g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
-        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
+        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
         AttnArgs at{};
         at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
         at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
         at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
-        at.ctx_split = sp ? 1 : 0; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
+        at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
         { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
         g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
-        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX, h->err_flag); }
         // FFN (HF:485-512)
         g = GemmArgs{};
-        g.A = sp ? h->Ys : h->Y; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+        g.A = sp ? h->Ys : h->Y; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
         { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
         g = GemmArgs{};
         g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
         g.alpha = w.f2_inv / mmee::kSplitScaleH1;
-        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1;
+        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }
         }
         // the layer wrote X densely in the numbering of stage `cur`
         x_phys = S_doc_off(cur);
@@ -885,6 +898,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         run_exit(nullptr, h->X, H, x_phys, true);
     }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
+    HIP_OK(h, hipMemcpyAsync(h->err_host, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipEventRecord(h->fwd_done, s));
     h->last_stream = s; h->has_fwd = true;
     HIP_OK(h, hipGetLastError());
@@ -898,11 +912,16 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
     HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * h->last_stages, hipMemcpyDeviceToHost));
     int err = 0;
     HIP_OK(h, hipMemcpy(&err, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (h->err_host) *h->err_host = 0;          // reported here
     if (n_stages_out) *n_stages_out = h->last_stages;
     for (int i = 0; i < h->last_stages && i < cap; ++i) {
         if (docs_out) docs_out[i] = sc[h->exit_stage[i]].n_docs;
         if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
     }
+    if (err & mmee::kErrSplitOverflow)
+        return fail(h, "ee_forward: split-precision overflow (flags %d): an activation left the range of the split-f16 planes (|LayerNorm out|, "
+                       "|Q/sqrt(d)|, |K|, |V|, |GELU out| <= 3750, |attention context| <= 937) and was clamped, so the result is WRONG; "
+                       "run this checkpoint with precision \"fp32\"", err);
     if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id, 8 = token_type id)", err);
     return 0;
 }

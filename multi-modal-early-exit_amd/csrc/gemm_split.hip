@@ -91,6 +91,7 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
     f32x4 lam = f32x4{1.f, 1.f, 1.f, 1.f};
     if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
     const float alpha = g.alpha;
+    float amax = 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -128,7 +129,7 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
                 // row leaves as one fully coalesced 16-byte-per-lane store (as the f32 output does) instead of two 8-byte
                 // scatters per lane.  Every lane takes part in the permute (rows >= M only skip the store).
                 f16x4 hi, lo;
-                split_f16x4(v, g.out_scale, hi, lo);
+                split_f16x4(row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f}, g.out_scale, hi, lo, amax);
                 const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
                 const bool take_lo = (lane & 2) != 0;
                 int4 piece;       // lane q: q = 0 -> hi of lanes 0,1; 1 -> hi of lanes 2,3; 2 -> lo of lanes 0,1; 3 -> lo of lanes 2,3
@@ -147,6 +148,7 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
             }
         }
     }
+    if (OUT_SPLIT) split_flag_overflow(amax, g.err_flag);
 }
 
 // Accumulator staging of the 16x16x32 form: tile (mi, ni) of the wave's 4x4 has col = lane & 15, rows 4 (lane >> 4) + reg.
@@ -166,6 +168,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
     f32x4 lam = f32x4{1.f, 1.f, 1.f, 1.f};
     if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
     const float alpha = g.alpha;
+    float amax = 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -201,7 +204,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
             }
             if (OUT_SPLIT) {
                 f16x4 hi, lo;
-                split_f16x4(v, g.out_scale, hi, lo);
+                split_f16x4(row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f}, g.out_scale, hi, lo, amax);
                 const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
                 const bool take_lo = (lane & 2) != 0;
                 int4 piece;
@@ -220,6 +223,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
             }
         }
     }
+    if (OUT_SPLIT) split_flag_overflow(amax, g.err_flag);
 }
 
 template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false>
@@ -494,25 +498,27 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
 // f32 rows -> split rows, and the |max| reduction that picks a weight tensor's scale
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, char* __restrict__ dst, const int* __restrict__ n_rows_ptr,
-                                                         int n_rows_static, int K, float scale) {
+                                                         int n_rows_static, int K, float scale, int* __restrict__ err_flag) {
     const int n_rows = n_rows_ptr ? *n_rows_ptr : n_rows_static;
     const int k4 = K / 4;
     const size_t total = (size_t)n_rows * k4;
+    float amax = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t r = i / k4;
         const int c = (int)(i - r * k4) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * K + c);
-        store_split4(dst + r * (size_t)K * 4, c, v, scale);
+        store_split4(dst + r * (size_t)K * 4, c, v, scale, amax);
     }
+    split_flag_overflow(amax, err_flag);
 }
 
 void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n_rows_static, int max_rows, int K, float scale, int num_cus,
-                       hipStream_t s) {
+                       hipStream_t s, int* err_flag) {
     size_t total = (size_t)max_rows * (K / 4);
     size_t blocks = (total + 255) / 256;
     int grid = (int)(blocks < (size_t)num_cus * 16 ? blocks : (size_t)num_cus * 16);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), n_rows_ptr, n_rows_static, K, scale);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), n_rows_ptr, n_rows_static, K, scale, err_flag);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, size_t n, float* __restrict__ out) {

@@ -147,10 +147,15 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // x * 0.5 * (1 + erf
 // whole contiguous 64-byte runs.
 // ---------------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& hi, f16x4& lo) {
+constexpr float kSplitClamp = 60000.0f;     // < 65504 = largest finite f16
+constexpr int kErrSplitOverflow = 16;       // err_flag bit: a value left the range of the split-f16 planes (it was clamped)
+// `amax` collects max |scale * x| BEFORE the clamp (one v_max3_f32 per pair): the caller raises kErrSplitOverflow in the
+// handle's err_flag when it exceeds kSplitClamp, so that a clamped (= wrong) result never goes unnoticed.
+__device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& hi, f16x4& lo, float& amax) {
 #pragma unroll
     for (int t = 0; t < 4; t += 2) {          // pairs: v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32
         f32x2 x = f32x2{v[t], v[t + 1]} * (f32x2)(scale);
+        amax = fmaxf(amax, fmaxf(fabsf(x[0]), fabsf(x[1])));
         x = __builtin_elementwise_min(__builtin_elementwise_max(x, (f32x2)(-60000.0f)), (f32x2)(60000.0f));
         const f16x2 h = __builtin_convertvector(x, f16x2);
         const f32x2 hf = __builtin_convertvector(h, f32x2);
@@ -160,9 +165,12 @@ __device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& 
     }
 }
 // store 4 consecutive columns [col, col+4) (col % 4 == 0) of a split row
-__device__ __forceinline__ void store_split4(void* row_base, int col, const f32x4& v, float scale) {
+__device__ __forceinline__ void split_flag_overflow(float amax, int* err_flag) {
+    if (err_flag && !(amax <= kSplitClamp)) atomicOr(err_flag, kErrSplitOverflow);      // NaN counts as overflow
+}
+__device__ __forceinline__ void store_split4(void* row_base, int col, const f32x4& v, float scale, float& amax) {
     f16x4 hi, lo;
-    split_f16x4(v, scale, hi, lo);
+    split_f16x4(v, scale, hi, lo, amax);
     char* p = reinterpret_cast<char*>(row_base) + (col >> 4) * 64 + (col & 15) * 2;
     *reinterpret_cast<f16x4*>(p) = hi;
     *reinterpret_cast<f16x4*>(p + 32) = lo;
@@ -208,6 +216,7 @@ struct GemmArgs {
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
     int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
     unsigned long long* clk_probe;   // diagnostic (ee_debug_gemm): per workgroup {shader cycles, 100 MHz ticks}; null in the path
+    int* err_flag;                   // split output: kErrSplitOverflow is raised when a value had to be clamped; may be null
 };
 
 struct AttnArgs {
@@ -227,6 +236,7 @@ struct AttnArgs {
     int ctx_split;
     float ctx_scale;
     float qkv_scale;                 // attention_split.hip: scale of the split Q | K | V rows (qkv then points to split rows)
+    int* err_flag;                   // ctx_split: kErrSplitOverflow when a context value had to be clamped; may be null
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -237,7 +247,7 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
 bool gemm_split_supports(int N, int K);
 // f32 rows -> split rows (n_rows_ptr null -> n_rows_static); src row r is src[row_src ? row_src[r] : r]
 void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n_rows_static, int max_rows, int K, float scale,
-                       int num_cus, hipStream_t s);
+                       int num_cus, hipStream_t s, int* err_flag = nullptr);
 void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);

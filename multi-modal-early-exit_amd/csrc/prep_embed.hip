@@ -325,9 +325,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                      char* __restrict__ dst_split, float split_scale) {
+                                                      char* __restrict__ dst_split, float split_scale, int* __restrict__ err_flag) {
     const int n_rows = *n_rows_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float amax = 0.f;
     for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
         f32x4 x[NV];
         const float* p = src + (size_t)(row_src ? row_src[r] : r) * H;
@@ -342,10 +343,11 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < H) store_split4(dst_split + (size_t)r * H * 4, c, x[i], split_scale);
+                if (c < H) store_split4(dst_split + (size_t)r * H * 4, c, x[i], split_scale, amax);
             }
         }
     }
+    split_flag_overflow(amax, err_flag);
 }
 
 // BEiT / DiT embeddings (BeitEmbeddings.forward): X[b*Pv + v] = (v == 0 ? cls_token : patch[b][v-1]) + position_embeddings[v]
@@ -440,7 +442,7 @@ void launch_pool_finish(const float* part, int chunks, int H, float count, float
 }
 
 void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
-                    const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split_v, float split_scale) {
+                    const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split_v, float split_scale, int* err_flag) {
     char* dst_split = reinterpret_cast<char*>(dst_split_v);
     int grid = (max_rows + 3) / 4;
     const int cap = num_cus * 8;
@@ -448,10 +450,10 @@ void launch_ln_rows(const float* src, float* dst, const int* row_src, const int*
     if (grid < 1) grid = 1;
     const int nv = (H + 255) / 256;
     switch (nv) {
-        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
-        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
-        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
-        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale); break;
+        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
+        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
+        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
+        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
     }
 }
 

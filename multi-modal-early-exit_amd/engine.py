@@ -242,6 +242,11 @@ class EarlyExitEngine:
 
     __call__ = forward
 
+    def check(self):
+        """Synchronise and raise ``MMEEError`` if the last forward flagged out-of-range inputs or a split-precision overflow
+        (``forward`` itself only enqueues; an unchecked error is also reported by the next ``forward`` call)."""
+        self.stage_counts()
+
     # ---- statistics of the last forward (both synchronise) ----------------------------------------------------------
     def stage_counts(self):
         n = self.E + 1

@@ -58,6 +58,25 @@ class EESequenceClassifierOutput(_ModelOutput):  # EE/models/EE_modules.py:231-2
                "gated_logits", "lte_output")
 
 
+def load_local_processor(path: str):
+    """The ``AutoProcessor`` the reference attaches to the model (``AutoProcessor.from_pretrained(model_weights,
+    apply_ocr=False)``, EE/models/LayoutLMv3.py:674-677; read by ``load_dataset`` through ``model.processor`` /
+    ``.tokenizer``, EE/utils.py:83-98) — from a LOCAL directory only (there is no hub access).  Returns None when the directory
+    holds no processor / tokenizer files or transformers cannot build one from them."""
+    import os
+    if not path or not os.path.isdir(path):
+        return None
+    if not any(os.path.exists(os.path.join(path, f)) for f in ("preprocessor_config.json", "processor_config.json", "tokenizer_config.json")):
+        return None
+    try:
+        from transformers import AutoProcessor
+        return AutoProcessor.from_pretrained(path, apply_ocr=False, local_files_only=True)
+    except Exception as e:  # noqa: BLE001 - a broken processor directory must not stop the model from loading
+        import warnings
+        warnings.warn(f"processor files under {path} could not be loaded ({type(e).__name__}: {e}); model.processor stays None")
+        return None
+
+
 class LayoutLMv3EEForSequenceClassification:
     """Drop-in for the reference class of the same name (inference only)."""
 
@@ -80,7 +99,10 @@ class LayoutLMv3EEForSequenceClassification:
             hidden_size=config.hidden_size, num_hidden_layers=config.num_hidden_layers)
         self.num_labels = config.num_labels
         self.apply_gating = str(ec.encoder_layer_strategy) == "gate"
-        self.processor = None          # offline: no AutoProcessor (EE/models/LayoutLMv3.py:674-677 fetches one)
+        # the reference fetches AutoProcessor(model_weights) from the hub (EE/models/LayoutLMv3.py:674-677); here
+        # from_pretrained attaches one when the checkpoint directory (or EE_config["model_weights"], if that is a local
+        # directory) holds processor files, else it stays None
+        self.processor = load_local_processor(str(config.EE_config.get("model_weights", "")))
         self.training = False
         self._weights = None
         if weights is not None:
@@ -100,6 +122,7 @@ class LayoutLMv3EEForSequenceClassification:
             cfg.EE_config.update({k: (str(v) if hasattr(v, "value") else v) for k, v in dict(ee).items()})
         m = cls(cfg, **kw)
         m.load_weights(load_checkpoint_tensors(path))
+        m.processor = load_local_processor(path) or m.processor
         return m
 
     # ---- nn.Module-ish surface the harness touches -------------------------------------------------------------------
@@ -157,7 +180,7 @@ class LayoutLMv3EEForSequenceClassification:
                                       "EarlyExitEngine.forward(want_hidden_cls=True) returns the CLS row of every layer")
         out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                              token_type_ids=token_type_ids, position_ids=position_ids),
-                        dump_all=True, want_all=True, want_head=True)
+                        dump_all=True, want_all=True, want_head=True, validate=True)
         return self._pack(out, labels, return_dict)
 
     def _pack(self, out: EngineOutput, labels, return_dict):
@@ -219,7 +242,7 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
             raise ValueError("pixel_values is required")
         if head_mask is not None or output_attentions or output_hidden_states:
             raise NotImplementedError("head_mask / attention maps / full hidden states are not part of the evaluation hot path")
-        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True)
+        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True, validate=True)
         return self._pack(out, labels, return_dict)
 
     __call__ = forward

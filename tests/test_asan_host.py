@@ -1,0 +1,92 @@
+"""Host-side AddressSanitizer run of the C-ABI (sanitizers stay on the CPU build): `make asan` compiles
+the host half of every translation unit with -fsanitize=address; a child python with the ASan runtime preloaded drives the
+entry points that run entirely on the host (ee_create's configuration rejections, ee_bucket_lut, argument checks of the
+policy / sweep / feed calls) and must exit cleanly with no ASan report."""
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+
+from .conftest import ROOT
+
+CSRC = os.path.join(ROOT, "multi-modal-early-exit_amd", "csrc")
+LIB = os.path.join(ROOT, "multi-modal-early-exit_amd", "libmmee_hip_asan.so")
+
+CHILD = r'''
+import ctypes as C, importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["MMEE_ROOT"])
+capi = importlib.import_module("multi-modal-early-exit_amd.capi")
+lib = capi.load()
+assert capi.lib_path().endswith("libmmee_hip_asan.so")
+# ee_bucket_lut: host only; the 1D / 2D LUTs of LayoutLMv3 (HF:392-413), plus refused arguments
+for nb, md, delta in ((32, 128, 1023), (64, 256, 1023), (4, 8, 0), (256, 4096, 5000)):
+    out = np.zeros(2 * delta + 1, np.uint8)
+    assert lib.ee_bucket_lut(nb, md, delta, out.ctypes.data_as(C.c_void_p)) == 0
+    assert out.max() < nb
+assert lib.ee_bucket_lut(2, 128, 10, np.zeros(21, np.uint8).ctypes.data_as(C.c_void_p)) != 0
+assert lib.ee_bucket_lut(32, 128, 10, None) != 0
+# ee_create: every configuration rejection happens before the device is touched
+def cfg(**kw):
+    c = capi.EEConfig()
+    c.abi_version = capi.ABI_VERSION
+    base = dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=100,
+                max_position_embeddings=66, type_vocab_size=1, pad_token_id=1, max_2d_position_embeddings=1024, coordinate_size=21,
+                shape_size=22, rel_pos_bins=32, max_rel_pos=128, rel_2d_pos_bins=64, max_rel_2d_pos=256, input_size=64, patch_size=16,
+                num_channels=3, num_labels=16, n_embedding_exits=0, n_encoder_exits=1, exit_head_num_layers=2, max_docs=4, max_text_len=32)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(c, k, v)
+    c.layer_norm_eps = 1e-5
+    c.encoder_exit_layers[0] = 1
+    return c
+bad = [dict(abi_version_bad=1), dict(hidden_size=100), dict(num_attention_heads=3), dict(coordinate_size=20), dict(num_labels=0),
+       dict(num_labels=65), dict(n_encoder_exits=65), dict(max_docs=0), dict(max_text_len=2000), dict(precision=1), dict(precision=2),
+       dict(exit_head_num_layers=3), dict(arch=7), dict(patch_size=10), dict(n_embedding_exits=4)]
+for kw in bad:
+    c = cfg(**{k: v for k, v in kw.items() if k != "abi_version_bad"})
+    if "abi_version_bad" in kw:
+        c.abi_version = 999
+    h = C.c_void_p()
+    rc = lib.ee_create(C.byref(c), C.byref(h))
+    assert rc != 0 and not h.value, kw
+    assert len(capi.last_error(None)) > 0
+h = C.c_void_p()
+assert lib.ee_create(None, C.byref(h)) != 0
+c = cfg()
+c.encoder_exit_layers[0] = 9          # exit layer beyond the depth
+assert lib.ee_create(C.byref(c), C.byref(h)) != 0
+rc = lib.ee_create(C.byref(cfg()), C.byref(h))      # valid configuration: refused only because this box has no GPU
+assert rc != 0 and "no HIP device" in capi.last_error(None), capi.last_error(None)
+# null handles / refused arguments of the other entry points
+assert lib.ee_forward(None, *([None] * 6), 1, 1, None, None, 0, *([None] * 9)) != 0
+assert lib.ee_destroy(None) == 0 and lib.ee_num_expected_tensors(None) == 0 and lib.ee_expected_tensor_name(None, 0) is None
+assert lib.ee_finalize(None) != 0 and lib.ee_profile(None, 1) != 0
+assert lib.ee_policy_scan(None, 0, 1, 1, None, None, None, None, None, None) != 0
+assert lib.ee_threshold_sweep(None, None, 1, 1, None, 1, None, None, None, None) != 0
+assert lib.ee_msp_table(None, None, 1, 1, 1, None, None, None) != 0
+assert lib.ee_temperature_fit(None, None, 1, 1, 2, 10, None, None, None, None, None, None) != 0
+assert lib.ee_preprocess_images(None, None, 1, 224, 10, None, 0, None, None, None) != 0
+assert lib.ee_preprocess_workspace_bytes(4, 224, 1000) > 4 * 1000 * 224 * 3
+assert lib.ee_collate_pad(None, None, None, 1, 1, 1, None, None, None, None) != 0
+print("ASAN_CHILD_OK")
+'''
+
+
+def _asan_runtime():
+    hits = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    return hits[-1] if hits else None
+
+
+def test_c_abi_host_paths_under_address_sanitizer():
+    rt = _asan_runtime()
+    if rt is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no ASan runtime / hipcc in this image")
+    subprocess.run(["make", "-C", CSRC, "asan", "-j4"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, LD_PRELOAD=rt, MMEE_LIB=LIB, MMEE_ROOT=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0:exitcode=97:protect_shadow_gap=0")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert "ERROR: AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_CHILD_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])

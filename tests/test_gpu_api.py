@@ -283,3 +283,80 @@ def test_dit_model_wrapper(pkg):
     assert len(out.exit_states) == 4 and len(out.exit_criteria) == 5 and out.loss is not None
     ee = m.early_exit(pixel_values=pix, thresholds=float(g["pol_thr1"]))
     assert np.array_equal(ee.exit_layer.cpu().numpy(), g["pol_exits1"])
+
+
+def test_checkpoint_round_trip(pkg, tmp_path):
+    """save_checkpoint -> LayoutLMv3EEForSequenceClassification.from_pretrained (EE/configs.py:389-411) -> the same logits as
+    load_weights, for float32 safetensors and for float16 / bfloat16 tensors (converted by ee_load_tensor), host and device."""
+    import torch
+    from safetensors.torch import save_file as save_torch
+    g = load_golden("tiny_ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    b = _batch(g)
+    b.pop("labels")
+
+    def logits_of(model):
+        out = model.forward(**b)
+        return torch.stack([s[0] for s in out.exit_states] + [out.logits]).cpu().numpy()
+
+    ref = logits_of(pkg.LayoutLMv3EEForSequenceClassification(cfg, W, max_docs=8, max_text_len=int(g["text_len"])))
+    np.testing.assert_allclose(ref[-1], g["logits"], rtol=0, atol=1e-4)
+    d32 = str(tmp_path / "f32")
+    pkg.save_checkpoint(d32, cfg, W)
+    m = pkg.LayoutLMv3EEForSequenceClassification.from_pretrained(d32, max_docs=8, max_text_len=int(g["text_len"]))
+    assert m.config.exit_config["exits"] == TINY_CASES["tiny_ramp"]["exits"] and m.processor is None
+    assert np.array_equal(logits_of(m), ref)                                   # same bits in, same bits out
+    for name, tdt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        Wl = {k: torch.from_numpy(v).to(tdt) for k, v in W.items()}
+        d = str(tmp_path / name)
+        pkg.save_checkpoint(d, cfg, W)                                           # config.json (its f32 tensor file is replaced below)
+        save_torch({k: v.contiguous() for k, v in Wl.items()}, str(tmp_path / name / "model.safetensors"))
+        want = logits_of(pkg.LayoutLMv3EEForSequenceClassification(cfg, {k: v.float().numpy() for k, v in Wl.items()}, max_docs=8,
+                                                                   max_text_len=int(g["text_len"])))
+        got = logits_of(pkg.LayoutLMv3EEForSequenceClassification.from_pretrained(d, max_docs=8, max_text_len=int(g["text_len"])))
+        assert np.array_equal(got, want), name                                 # host f16 / bf16 -> f32 conversion is exact
+        dev = pkg.LayoutLMv3EEForSequenceClassification(cfg, {k: v.cuda() for k, v in Wl.items()}, max_docs=8,
+                                                        max_text_len=int(g["text_len"]))
+        assert np.array_equal(logits_of(dev), want), name + " (device tensors)"
+        assert float(np.abs(want - ref).max()) > 0                             # the rounding really changed the weights
+    eng = pkg.EarlyExitEngine.from_pretrained(d32, max_docs=8, max_text_len=int(g["text_len"]))
+    out = eng.forward(b["input_ids"], b["attention_mask"], b["bbox"], b["pixel_values"], dump_all=True, want_all=True)
+    assert np.array_equal(out.all_logits[-1].cpu().numpy(), ref[-1])
+    eng.close()
+    W2 = dict(W)
+    W2["classifier.dense.weight"] = W2["classifier.dense.weight"][:, :-1]
+    bad = str(tmp_path / "bad")
+    pkg.save_checkpoint(bad, cfg, W2)
+    with pytest.raises(pkg.capi.MMEEError, match="shape"):
+        pkg.LayoutLMv3EEForSequenceClassification.from_pretrained(bad, max_docs=8, max_text_len=int(g["text_len"]))
+
+
+def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
+    """calibrate() of EE/eval.py:277-346 on the device (temperatures) + the restated ECE -> config["calibration_metrics"] ->
+    Policy.accuracy_calibration_heuristic (EE/policy.py:55-111), with no hand-supplied metric."""
+    rng = np.random.default_rng(12)
+    E1, N, K = 5, 900, 16
+    labels = rng.integers(0, K, N)
+    sharp = np.linspace(0.6, 2.2, E1)[:, None, None]                         # later exits are more accurate
+    val = rng.standard_normal((E1, N, K)) * 1.5
+    val[:, np.arange(N), labels] += 1.2 * sharp[:, 0]
+    val *= np.array([3.0, 0.5, 2.0, 1.0, 4.0])[:, None, None]                # each exit mis-calibrated by a different factor
+    test = val[:, ::-1].copy()
+    cal, metrics = pkg.calibration.calibrate(val, labels, test)
+    assert set(metrics) == {"ece", "accuracy", "temperature", "average_confidence"} and all(len(v) == E1 for v in metrics.values())
+    T = np.array(metrics["temperature"])
+    np.testing.assert_allclose(cal, test / T[:, None, None], rtol=1e-12)
+    for e in range(E1):
+        assert abs(T[e] - oracle.fit_temperature(val[e], labels)) < 2e-3 * T[e]
+        assert abs(metrics["ece"][e] - pkg.calibration.expected_calibration_error(labels, val[e] / T[e])) < 1e-12
+        assert metrics["ece"][e] < pkg.calibration.expected_calibration_error(labels, val[e]) + 1e-3    # scaling does not hurt calibration
+        assert abs(metrics["accuracy"][e] - np.mean(val[e].argmax(-1) == labels)) < 1e-12
+    cfgp = {"exit_threshold": 0.5, "device": "cpu", "epsilon": 0.05, "calibration_metrics": metrics}
+    ex, pred, dist = pkg.Policy(cal, cfgp).accuracy_calibration_heuristic()
+    thr = oracle.heuristic_thresholds(metrics["accuracy"], metrics["ece"], 0.05)
+    ex_o, pred_o, _ = oracle.policy_scan(cal, thr)
+    near = np.abs(oracle.softmax64(cal).max(-1) - thr[:, None]).min(0) < 1e-12
+    assert np.array_equal(ex[~near], ex_o[~near]) and near.sum() < 3
+    np.testing.assert_array_equal(pred.numpy()[~near], pred_o[~near])
+    assert abs(sum(dist.values()) - 1.0) < 1e-12 and len(np.unique(ex)) >= 2

@@ -163,3 +163,47 @@ def test_create_rejects_bad_configs_with_a_message(pkg, over, needle):
     rc = lib.ee_create(C.byref(_base_c_config(pkg, **over)), C.byref(h))
     assert rc != 0 and not h.value
     assert needle.lower() in pkg.capi.last_error(None).lower(), pkg.capi.last_error(None)
+
+
+def test_ece_restatement_hand_cases(pkg):
+    """expected_calibration_error with the reference's arguments (EE/metrics.py:479-498); parity unpinned (the remote metric's
+    code is unavailable), so the pins are cases small enough to do by hand."""
+    ece = pkg.calibration.expected_calibration_error
+    conf = np.array([0.6, 0.7, 0.8, 0.9])
+    P = np.stack([conf, 1.0 - conf], axis=1)
+    y = np.array([0, 1, 0, 0])                       # correct = [1, 0, 1, 1]
+    # n_bins = min(N-1, 100) = 3; edges [0.6, 0.7, 0.8, 1.0]; bins {0.6}, {0.7}, {0.8, 0.9}; acc 1, 0, 1; upper edges 0.7, 0.8, 1.0
+    assert abs(ece(y, P) - (0.25 * 0.3 + 0.25 * 0.8 + 0.5 * 0.0)) < 1e-12
+    assert abs(ece(y, P, proxy="center") - (0.25 * abs(1 - 0.65) + 0.25 * 0.75 + 0.5 * abs(1 - 0.9))) < 1e-12
+    assert abs(ece(y, P, n_bins=2, scheme="equal-range") - (0.0 + 1.0 * abs(0.75 - 1.0))) < 1e-12   # all four in [0.5, 1]
+    # logits are softmaxed first (EE/metrics.py:480-481), and a tie on an edge goes to the right bin
+    L = np.log(P)
+    assert abs(ece(y, L) - ece(y, P)) < 1e-12
+    rng = np.random.default_rng(0)
+    Z = rng.standard_normal((5000, 16)) * 3
+    yy = np.array([rng.choice(16, p=pr) for pr in np.exp(Z - Z.max(1, keepdims=True)) / np.exp(Z - Z.max(1, keepdims=True)).sum(1, keepdims=True)])
+    e_cal, e_over = ece(yy, Z), ece(yy, 3.0 * Z)
+    assert 0.0 <= e_cal < 0.05 < e_over <= 1.0       # labels drawn from softmax(Z): calibrated; sharpened logits are over-confident
+    with pytest.raises(ValueError):
+        ece(np.zeros(3), np.zeros((4, 2)))
+
+
+def test_local_processor_loader(pkg, tmp_path):
+    """model.processor comes from a LOCAL directory (the reference fetches it from the hub, EE/models/LayoutLMv3.py:674-677)."""
+    assert pkg.load_local_processor(str(tmp_path)) is None and pkg.load_local_processor("microsoft/layoutlmv3-base") is None
+    transformers = pytest.importorskip("transformers")
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3, "<mask>": 4, "h": 5, "i": 6, "\u0120": 7, "hi": 8, "\u0120hi": 9}
+    d = tmp_path / "proc"
+    d.mkdir()
+    (d / "vocab.json").write_text(json.dumps(vocab))
+    (d / "merges.txt").write_text("#version: 0.2\nh i\n\u0120 hi\n")
+    try:
+        tok = transformers.LayoutLMv3TokenizerFast(vocab_file=str(d / "vocab.json"), merges_file=str(d / "merges.txt"))
+        proc = transformers.LayoutLMv3Processor(transformers.LayoutLMv3ImageProcessor(apply_ocr=False), tok)
+        proc.save_pretrained(str(d))
+    except Exception as e:  # noqa: BLE001
+        pytest.skip(f"cannot build a local LayoutLMv3 processor with this transformers: {e}")
+    got = pkg.load_local_processor(str(d))
+    assert got is not None and hasattr(got, "tokenizer")
+    enc = got.tokenizer(["hi", "hi"], boxes=[[1, 2, 3, 4], [5, 6, 7, 8]], padding="max_length", max_length=8, truncation=True)
+    assert len(enc["input_ids"]) == 8 and enc["input_ids"][0] == 0
