@@ -22,6 +22,7 @@ def _gap_thresholds(conf, release=0.12):
     E1, n = conf.shape
     thr = np.full(E1, 2.0)
     active = np.ones(n, dtype=bool)
+    margin = 1.0
     for e in range(E1 - 1):
         c = np.sort(conf[e, active])
         if len(c) < 2:
@@ -30,8 +31,9 @@ def _gap_thresholds(conf, release=0.12):
         lo, hi = max(1, k - 3), min(len(c) - 1, k + 3)
         j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
         thr[e] = 0.5 * (c[j - 1] + c[j])
+        margin = min(margin, float(np.abs(conf[e, active] - thr[e]).min()))     # only documents that reach the exit are tested
         active &= ~(conf[e] > thr[e])
-    return thr
+    return thr, margin
 
 
 def _config3(pkg):
@@ -102,8 +104,8 @@ def test_config3_full_size_properties(pkg, oracle):
     np.testing.assert_allclose(store, oracle.temperature_scale(_np(raw.all_logits).astype(np.float64), temps), rtol=1e-6, atol=1e-7)
     conf = oracle.softmax64(store).max(-1)
     np.testing.assert_allclose(_np(full.all_crit), conf, rtol=0, atol=2e-6)             # criterion = max softmax of logits / T
-    thr = _gap_thresholds(conf, release=0.12)
-    assert np.abs(conf[:-1] - thr[:-1, None]).min() > 1e-6
+    thr, margin = _gap_thresholds(conf, release=0.12)
+    assert margin > 1e-6, margin
     ex_ref, _, _ = oracle.policy_scan(store, thr)
     out = eng.forward(*args, thresholds=thr, temperatures=temps, validate=True)
     ex = _np(out.exit_layer)
