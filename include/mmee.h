@@ -223,6 +223,12 @@ int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const
                         int32_t K, int32_t epi, int32_t out_split, float a_scale, float w_scale, float out_scale,
                         const int32_t* row_src, int32_t rows_A, int32_t iters, float* ms_out, void* stream);
 
+/* Diagnostic of the two-heads-per-item attention kernel (attention_pair.hip): with MMEE_ATTN_STAMPS=1 in the environment the
+ * launches run a build with in-kernel s_memtime stamps; this call synchronises, copies the eight phase sums (shader cycles summed over
+ * waves: 0 wait for the tile's LDS-DMA, 1 DMA issue, 2 bias gathers, 3 Q K^T MFMAs, 4 / 5 softmax + P V of head A / B, 6 item prologue,
+ * 7 barrier) to out8 and clears them.  Timing shares only; never part of the path. */
+int ee_debug_attn_stamps(uint64_t* out8);
+
 /* Host-only helper (no GPU needed): the relative_position_bucket LUT (HF modeling_layoutlmv3.py:392-413) over
  * delta in [-max_delta, max_delta]; out_host has 2*max_delta+1 entries, index = delta + max_delta.  Exposed so the LUT
  * the kernels use can be pinned against the HF-generated golden table. */

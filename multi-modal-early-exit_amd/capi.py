@@ -68,6 +68,7 @@ SYMBOLS = {
     "ee_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ee_debug_gemm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float, C.c_float, C.c_float, _vp,
                                       _i32, _i32, C.POINTER(C.c_float), _vp]),
+    "ee_debug_attn_stamps": (C.c_int, [_vp]),
     "ee_temperature_fit": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ee_preprocess_images": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, C.c_size_t, _vp, _vp, _vp]),
     "ee_preprocess_workspace_bytes": (C.c_size_t, [_i32, _i32, _i32]),

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -731,6 +732,9 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     const bool sp = h->split;
     if (sp && !beit)     // the first QKV projection reads split-f16 rows; later layers get them from the LayerNorm kernel
         mmee::launch_split_rows(h->X, h->Xs, &h->counts[0].n_rows, 0, max_rows, H, mmee::kSplitScaleX, cus, s, h->err_flag);
+    // split precision: two heads per work item (attention_pair.hip) unless MMEE_ATTN_V=1 asks for the one-head kernel (A/B switch)
+    static const bool force_v1 = [] { const char* e = getenv("MMEE_ATTN_V"); return e && e[0] == '1'; }();
+    auto use_pair = [&](const AttnArgs& at) { return !force_v1 && mmee::attention_pair_supports(at, c.max_rel_pos, c.max_rel_2d_pos); };
     auto run_gemm = [&](const GemmArgs& g, int epi) {
         if (sp) launch_gemm_split(g, epi, max_rows, cus, s);
         else launch_gemm_f32(g, epi, AMODE_ROWS, max_rows, cus, s);
@@ -829,7 +833,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
             at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
             at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
-            { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
+            { ProfScope ps(h, P_ATTN, s); if (sp && use_pair(at)) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
             g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
             g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
@@ -858,7 +862,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
         at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
         at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
-        { ProfScope ps(h, P_ATTN, s); if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
+        { ProfScope ps(h, P_ATTN, s); if (sp && use_pair(at)) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
@@ -1080,6 +1084,15 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
         set_gemm_wgs_per_cu(0);
     }
     if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_debug_gemm: launch failed");
+    return 0;
+}
+
+int ee_debug_attn_stamps(uint64_t* out8) {
+    unsigned long long* d = mmee::attention_pair_stamps();
+    if (!out8 || !d) return fail(nullptr, "ee_debug_attn_stamps: no stamped launch has run (set MMEE_ATTN_STAMPS=1 before the first forward)");
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out8, d, 64, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(nullptr, "ee_debug_attn_stamps: copy failed");
+    (void)hipMemset(d, 0, 64);
     return 0;
 }
 

@@ -251,6 +251,9 @@ void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n
 void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
+unsigned long long* attention_pair_stamps();
+bool attention_pair_supports(const AttnArgs& a, int max_rel_pos, int max_rel_2d_pos);
+void launch_attention_pair(const AttnArgs& a, int max_docs, int num_cus, int max_rel_pos, int max_rel_2d_pos, int any_masked, hipStream_t s);
 size_t gemm_f32_lds_bytes();
 void set_gemm_wgs_per_cu(int n);
 void launch_gemm_f32_stamped(const GemmArgs& a, int epi, int grid, hipStream_t s);   // diagnostic build with in-kernel stamps
