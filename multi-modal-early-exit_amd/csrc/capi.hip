@@ -68,6 +68,7 @@ struct ee_handle {
     float *Xs = nullptr, *Ys = nullptr;           // split-f16 copies of X / Y rows (MMEE_PREC_F32_SPLIT)
     float* absmax_dev = nullptr;
     bool split = false;
+    float* cls_f32 = nullptr;                     // split mode: CLS rows of the active documents rebuilt from the split planes
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
     int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
     int* queue_heads = nullptr;                   // one work-queue counter per persistent launch of a forward
@@ -417,6 +418,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
             rc |= dev_alloc(h, &h->Xs, rows * H);
             rc |= dev_alloc(h, &h->Ys, rows * H);
             rc |= dev_alloc(h, &h->absmax_dev, 4);
+            rc |= dev_alloc(h, &h->cls_f32, Bm * H);
         }
         rc |= dev_alloc(h, &h->vis_raw, Bm * NP * H);
         rc |= dev_alloc(h, &h->text_part, Bm * tch * H);
@@ -865,31 +867,41 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         { ProfScope ps(h, P_ATTN, s); if (sp && use_pair(at)) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
-        g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
+        g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = rs;
+        g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
         g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
         g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX, h->err_flag); }
+        // split mode: the LayerNorm output exists only as split planes (22 bits); its readers (next GEMM, residual adds, exit heads) take it from there
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX, h->err_flag); }
         // FFN (HF:485-512)
         g = GemmArgs{};
         g.A = sp ? h->Ys : h->Y; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
         { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
         g = GemmArgs{};
-        g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H;
+        g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = sp ? h->Ys : h->Y; g.ldr = H;
+        g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
         g.alpha = w.f2_inv / mmee::kSplitScaleH1;
         g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
         { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }
+        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }
         }
         // the layer wrote X densely in the numbering of stage `cur`
         x_phys = S_doc_off(cur);
         use_row_src = false;
+        const bool x_is_split = sp && !beit;          // LayoutLMv3, split mode: the layer's output lives in Xs only
+        const float xs_inv = x_is_split ? 1.0f / mmee::kSplitScaleX : 0.f;
         if (out_hidden_cls)
-            launch_gather_cls(h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs,
-                              out_hidden_cls + (size_t)(l + 1) * B * H, B, s);
+            launch_gather_cls(x_is_split ? h->Xs : h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs,
+                              out_hidden_cls + (size_t)(l + 1) * B * H, B, s, xs_inv);
         if (next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1) {
-            run_exit(&h->enc_heads[next_enc], h->X, H, x_phys, false);
+            if (x_is_split) {
+                launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, xs_inv);
+                run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);
+            } else {
+                run_exit(&h->enc_heads[next_enc], h->X, H, x_phys, false);
+            }
             ++next_enc;
         }
     }
@@ -898,6 +910,9 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         launch_patch_mean(h->X, H, x_phys, S_doc_off(cur), &h->counts[cur].n_docs, h->pooled[0], B, s);
         launch_ln_rows(h->pooled[0], h->pooled[0], nullptr, &h->counts[cur].n_docs, B, H, h->ln_g, h->ln_b, c.layer_norm_eps, cus, s);
         run_exit(nullptr, h->pooled[0], H, nullptr, true);
+    } else if (sp && L > 0) {
+        launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
+        run_exit(nullptr, h->cls_f32, H, nullptr, true);
     } else {
         run_exit(nullptr, h->X, H, x_phys, true);
     }

@@ -211,22 +211,27 @@ void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, cons
 }
 
 // out[orig][:] = X[x_phys[i]][:]   (CLS rows, parity/debug output)
+// CLS row of every active document -> out[doc_orig ? doc_orig[i] : i].  split_inv != 0: X holds split-f16 rows (1 / scale = split_inv)
 __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict__ X, int H, const int* __restrict__ x_phys,
                                                          const int* __restrict__ doc_orig, const int* __restrict__ n_docs_ptr,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, float split_inv) {
     const int n = *n_docs_ptr;
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         const float* src = X + (size_t)x_phys[i] * H;
-        float* dst = out + (size_t)doc_orig[i] * H;
-        for (int c = threadIdx.x; c < H; c += 256) dst[c] = src[c];
+        float* dst = out + (size_t)(doc_orig ? doc_orig[i] : i) * H;
+        if (split_inv != 0.f) {
+            for (int c = 4 * threadIdx.x; c < H; c += 1024) *reinterpret_cast<f32x4*>(dst + c) = load_split4(src, c, split_inv);
+        } else {
+            for (int c = threadIdx.x; c < H; c += 256) dst[c] = src[c];
+        }
     }
 }
 
 void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr, float* out,
-                       int max_docs, hipStream_t s) {
+                       int max_docs, hipStream_t s, float split_inv) {
     int grid = max_docs < 2048 ? max_docs : 2048;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(gather_cls_kernel, dim3(grid), dim3(256), 0, s, X, H, x_phys, doc_orig, n_docs_ptr, out);
+    hipLaunchKernelGGL(gather_cls_kernel, dim3(grid), dim3(256), 0, s, X, H, x_phys, doc_orig, n_docs_ptr, out, split_inv);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -119,7 +119,8 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
                 }
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                    v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
+                    else v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
                 }
                 if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
             }
@@ -198,7 +199,8 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
                 }
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                    v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
+                    else v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
                 }
                 if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
             }

@@ -175,6 +175,15 @@ __device__ __forceinline__ void store_split4(void* row_base, int col, const f32x
     *reinterpret_cast<f16x4*>(p) = hi;
     *reinterpret_cast<f16x4*>(p + 32) = lo;
 }
+// 4 consecutive columns [col, col+4) of a split row back to f32: (hi + lo) * inv_scale — exact: hi + lo carries <= 23 significant bits
+__device__ __forceinline__ f32x4 load_split4(const void* row_base, int col, float inv_scale) {
+    const char* p = reinterpret_cast<const char*>(row_base) + (col >> 4) * 64 + (col & 15) * 2;
+    const f16x4 hi = *reinterpret_cast<const f16x4*>(p), lo = *reinterpret_cast<const f16x4*>(p + 32);
+    f32x4 r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r[t] = ((float)hi[t] + (float)lo[t]) * inv_scale;
+    return r;
+}
 // activation scales of the split planes (powers of two; see DESIGN.md "split precision")
 constexpr float kSplitScaleX = 16.0f;     // LayerNorm outputs (|x| up to a few tens)
 constexpr float kSplitScaleCtx = 64.0f;   // attention context (convex combinations of V rows)
@@ -197,6 +206,7 @@ struct GemmArgs {
     int ldc;
     const float* resid;          // EPI_RESID: C = acc + bias + resid[resid_row_src ? resid_row_src[r] : r]
     int ldr;
+    float resid_split_inv;       // != 0: resid points to split-f16 rows (of ldr columns) scaled by 1 / resid_split_inv; 0: f32 rows
     const int* resid_row_src;
     const int* m_ptr;            // device pointer to M (rows or docs of the active stage); null -> m_static
     int m_static;

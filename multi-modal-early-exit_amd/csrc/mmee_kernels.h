@@ -109,8 +109,9 @@ void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s);
 void launch_decide(const DecideArgs& a, hipStream_t s);
 void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,
                          const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s);
+// out[doc_orig ? doc_orig[i] : i] = CLS row of active document i; split_inv != 0: X holds split-f16 rows scaled by 1 / split_inv
 void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr,
-                       float* out, int max_docs, hipStream_t s);
+                       float* out, int max_docs, hipStream_t s, float split_inv = 0.f);
 void launch_policy_scan(const double* logits, int E1, int N, int K, const double* thr_dev, int* exits, double* pred,
                         double* conf, int* counts, hipStream_t s);
 void launch_threshold_sweep(const double* conf, const unsigned char* correct, int E1, int N, const double* thr, int V,
