@@ -155,35 +155,33 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
 // Accumulator staging of the 16x16x32 form: tile (mi, ni) of the wave's 4x4 has col = lane & 15, rows 4 (lane >> 4) + reg.
 // One 32-row half (mi = 2 half, 2 half + 1) is written to the wave's [32][64] f32 staging block; the column index is XOR-ed with
 // 16 on rows whose (row >> 2) is odd, so the two 16-lane groups of a 32-lane write group hit disjoint banks.
-template <int EPI, bool OUT_SPLIT, int WN>
+// RB = rows staged at a time (32: 8 KB per wave; 16: 4 KB per wave, so that the 16 waves' staging fits ONE ring slot and the other
+// slot can already receive the next tile's first stage while this epilogue runs).
+template <int EPI, bool OUT_SPLIT, int WN, int RB>
 __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* smem, f32x4 (&acc)[4][4], int m0, int n0, int M,
-                                                   int wave, int lane) {
+                                                   int wave, int lane, const f32x4 bv, const f32x4 lam) {
     const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, gq = lane >> 4;
-    float* stg = smem + wave * (32 * 64);
+    float* stg = smem + wave * (RB * 64);
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wc * 64 + c4;
-    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
     const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
-    f32x4 lam = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
     const float alpha = g.alpha;
     float amax = 0.f;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 64 / RB; ++half) {
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
+        for (int m2 = 0; m2 < RB / 16; ++m2)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 16 * m2 + 4 * gq + e;                      // (r >> 2) & 1 == gq & 1
-                    stg[r * 64 + ((ni * 16 + l15) ^ (16 * (gq & 1)))] = acc[2 * half + m2][ni][e];
+                    stg[r * 64 + ((ni * 16 + l15) ^ (16 * (gq & 1)))] = acc[(RB / 16) * half + m2][ni][e];
                 }
-        const int rbase = m0 + wr * 64 + half * 32 + (lane >> 4);
+        const int rbase = m0 + wr * 64 + half * RB + (lane >> 4);
 #pragma unroll 4
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < RB / 4; ++j) {
             const int rl = (lane >> 4) + 4 * j;
             const int row = rbase + 4 * j;
             f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (c4 ^ (16 * ((rl >> 2) & 1))));
@@ -277,10 +275,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     const unsigned w_row16 = (unsigned)A_BYTES + (unsigned)(wc * 64 + l15) * ROWB;
     const char* sbytes = reinterpret_cast<const char*>(smem);
 
-    for (;; tile += gridDim.x) {
-        int tm, tn;
+    // HANDOVER (the default configuration): the epilogue stages through ONE ring slot (4 KB per wave), so the next tile is drawn
+    // from the queue as soon as the k-loop ends and its first stage lands in the other slot while the epilogue runs.
+    constexpr bool HANDOVER = Cfg::MF == 16 && NST == 2 && Cfg::NW * 4096 <= STAGE_BYTES;
+
+    auto pop = [&](int& tm, int& tn) __attribute__((always_inline)) -> bool {
         if (g.tile_counter) {
-            bool got = false;
             while (q_try < 8) {
                 const int q = (my_xcd + q_try) & 7;
                 if (tid == 0) *q_slot = atomicAdd(g.tile_counter + 16 * q, 1);
@@ -293,51 +293,72 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 if (grp < n_groups) {
                     tn = r / GM;
                     tm = grp * GM + (r - tn * GM);
-                    if (tm < tiles_m) { got = true; break; }
+                    if (tm < tiles_m) return true;
                     continue;
                 }
                 ++q_try;
             }
-            if (!got) break;
-        } else {
-            if (tile >= n_tiles) break;
-            tm = tile / tiles_n;
-            tn = tile - tm * tiles_n;
+            return false;
         }
-        const int m0 = __builtin_amdgcn_readfirstlane(tm * BM), n0 = __builtin_amdgcn_readfirstlane(tn * BN);
+        if (tile >= n_tiles) return false;
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+        tile += gridDim.x;
+        return true;
+    };
 
-        // per-tile DMA sources: SGPR base + 32-bit lane offset (A rows may be gathered; row_src is increasing).
-        // Wave w owns A pieces w, w + NW, ... and W pieces likewise.
-        const int first = g.row_src ? g.row_src[m0] : m0;
+    // per-tile DMA sources: SGPR base + 32-bit lane offset (A rows may be gathered; row_src is increasing).
+    // Wave w owns A pieces w, w + NW, ... and W pieces likewise.
+    struct TileCtx {
+        int m0, n0;
         unsigned a_voff[PA], w_voff[PW];
+        unsigned long long a_base, w_base;
+    };
+    auto setup = [&](int tm, int tn, TileCtx& t) __attribute__((always_inline)) {
+        t.m0 = __builtin_amdgcn_readfirstlane(tm * BM);
+        t.n0 = __builtin_amdgcn_readfirstlane(tn * BN);
+        const int first = g.row_src ? g.row_src[t.m0] : t.m0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int piece = wave + Cfg::NW * j;
-            int ra = m0 + Cfg::PROWS * piece + p_row;
+            int ra = t.m0 + Cfg::PROWS * piece + p_row;
             ra = ra < M ? ra : M - 1;
             const int sa = g.row_src ? g.row_src[ra] : ra;
-            a_voff[j] = (unsigned)(sa - first) * (unsigned)g.lda * 4u + ((piece & 1) ? chunk_odd : chunk_even);
+            t.a_voff[j] = (unsigned)(sa - first) * (unsigned)g.lda * 4u + ((piece & 1) ? chunk_odd : chunk_even);
         }
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             const int piece = wave + Cfg::NW * j;
-            w_voff[j] = (unsigned)(Cfg::PROWS * piece + p_row) * (unsigned)g.K * 4u + ((piece & 1) ? chunk_odd : chunk_even);
+            t.w_voff[j] = (unsigned)(Cfg::PROWS * piece + p_row) * (unsigned)g.K * 4u + ((piece & 1) ? chunk_odd : chunk_even);
         }
         const unsigned long long a_base_v = (unsigned long long)(size_t)g.A + (unsigned long long)first * (unsigned)g.lda * 4ull;
-        const unsigned long long w_base_v = (unsigned long long)(size_t)g.W + (unsigned long long)n0 * (unsigned)g.K * 4ull;
-        const unsigned long long a_base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a_base_v >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(a_base_v & 0xffffffffu));
-        const unsigned long long w_base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w_base_v >> 32)) << 32) |
-                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(w_base_v & 0xffffffffu));
-        auto issue = [&](int kt, int buf) {
-            const unsigned long long koff = (unsigned long long)kt * (unsigned)ROWB;
-            const unsigned dst = lds0 + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
+        const unsigned long long w_base_v = (unsigned long long)(size_t)g.W + (unsigned long long)t.n0 * (unsigned)g.K * 4ull;
+        t.a_base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a_base_v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(a_base_v & 0xffffffffu));
+        t.w_base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(w_base_v >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)(w_base_v & 0xffffffffu));
+    };
+    auto issue = [&](const TileCtx& t, int kt, int buf) __attribute__((always_inline)) {
+        const unsigned long long koff = (unsigned long long)kt * (unsigned)ROWB;
+        const unsigned dst = lds0 + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
-            for (int j = 0; j < PA; ++j) dma_piece(a_voff[j], a_base + koff, dst + (unsigned)(Cfg::NW * j) * 1024u);
+        for (int j = 0; j < PA; ++j) dma_piece(t.a_voff[j], t.a_base + koff, dst + (unsigned)(Cfg::NW * j) * 1024u);
 #pragma unroll
-            for (int j = 0; j < PW; ++j) dma_piece(w_voff[j], w_base + koff, dst + A_BYTES + (unsigned)(Cfg::NW * j) * 1024u);
-        };
+        for (int j = 0; j < PW; ++j) dma_piece(t.w_voff[j], t.w_base + koff, dst + A_BYTES + (unsigned)(Cfg::NW * j) * 1024u);
+    };
 
+    TileCtx cur;
+    int buf0 = 0;                                    // ring slot of the current tile's stage 0
+    {
+        int tm, tn;
+        if (!pop(tm, tn)) return;                    // uniform over the workgroup (diagnostic clock probe: nothing to report)
+        setup(tm, tn, cur);
+    }
+    // ring: stage kt lives in slot (buf0 + kt) % NST; NST - 1 stages are in flight ahead of the one being consumed
+    issue(cur, 0, buf0);
+    if (NST == 3 && nk > 1) issue(cur, 1, 1);
+    for (;;) {
+        const int m0 = cur.m0, n0 = cur.n0;
         f32x16 acc[2][2];
         f32x4 acc16[4][4];
         if constexpr (Cfg::MF == 32) {
@@ -354,10 +375,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
-        // ring: stage kt lives in slot kt % NST; NST - 1 stages are in flight ahead of the one being consumed
-        issue(0, 0);
-        if (NST == 3 && nk > 1) issue(1, 1);
-        int buf = 0, bufn = NST - 1;                 // slots of stage kt and of stage kt + NST - 1
+        int buf = buf0, bufn = (buf0 + NST - 1) % NST;     // slots of stage kt and of stage kt + NST - 1
         for (int kt = 0; kt < nk; ++kt) {
             // my pieces of stage kt have landed (NST == 3: the pieces of stage kt + 1 may still be in flight), then the
             // barrier: everyone's have, and everyone has left stage kt - 1, whose slot the next issue overwrites
@@ -372,7 +390,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
-            if (kt + NST - 1 < nk && !(dbg & 1)) issue(kt + NST - 1, bufn);
+            if (kt + NST - 1 < nk && !(dbg & 1)) issue(cur, kt + NST - 1, bufn);
             const char* sb = sbytes + buf * STAGE_BYTES;
             if constexpr (Cfg::MF == 16) {
                 // A fragments of the four 16-row tiles stay in registers; W fragments come one 16-column tile at a time
@@ -418,12 +436,46 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             buf = buf == NST - 1 ? 0 : buf + 1;
             bufn = bufn == NST - 1 ? 0 : bufn + 1;
         }
-        __syncthreads();                             // every wave is done with the ring before it becomes the staging area
+        __syncthreads();                             // every wave is done with the ring before (part of) it becomes the staging area
+        // the epilogue's per-column constants are fetched BEFORE the hand-over DMA is issued: hipcc waits vmcnt(0) at the first use of
+        // an ordinary load, which would otherwise also wait for the LDS-DMA pieces issued below
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, lam = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (Cfg::MF == 16) {
+            const int col = n0 + wc * 64 + (lane & 15) * 4;
+            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (g.col_scale) lam = *reinterpret_cast<const f32x4*>(g.col_scale + col);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv), "+v"(lam) :: "memory");
+        }
+        // draw the next tile now; with HANDOVER its first stage goes into the slot the last stage did NOT use, and the epilogue
+        // below stages through the last stage's slot only
+        TileCtx nxt;
+        bool have;
+        {
+            int tm, tn;
+            have = pop(tm, tn);
+            if (have) setup(tm, tn, nxt);
+        }
+        const int last_slot = (buf0 + nk - 1) % NST;
+        const int nbuf0 = HANDOVER ? (last_slot ^ 1) : 0;
+        if (HANDOVER && have) issue(nxt, 0, nbuf0);
         if (!(dbg & 8)) {
-            if constexpr (Cfg::MF == 16) split_store_tile16<EPI, OUT_SPLIT, WN>(g, smem, acc16, m0, n0, M, wave, lane);
-            else split_store_tile<EPI, OUT_SPLIT, WN>(g, smem, acc, m0, n0, M, wave, lane);
+            if constexpr (Cfg::MF == 16) {
+                if constexpr (HANDOVER)
+                    split_store_tile16<EPI, OUT_SPLIT, WN, 16>(g, smem + last_slot * (STAGE_BYTES / 4), acc16, m0, n0, M, wave, lane, bv, lam);
+                else
+                    split_store_tile16<EPI, OUT_SPLIT, WN, 32>(g, smem, acc16, m0, n0, M, wave, lane, bv, lam);
+            } else {
+                split_store_tile<EPI, OUT_SPLIT, WN>(g, smem, acc, m0, n0, M, wave, lane);
+            }
         }
         __syncthreads();
+        if (!have) break;
+        cur = nxt;
+        buf0 = nbuf0;
+        if (!HANDOVER) {
+            issue(cur, 0, 0);
+            if (NST == 3 && nk > 1) issue(cur, 1, 1);
+        }
     }
     if (DIAG && g.clk_probe && threadIdx.x == 0) {      // diagnostic: shader clock = d(memtime) / d(memrealtime) * 100 MHz
         g.clk_probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
