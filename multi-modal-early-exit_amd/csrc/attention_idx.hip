@@ -1,0 +1,490 @@
+// Fused LayoutLMv3 self-attention, split-f16 operands, relative-position bias from a per-document PAIR INDEX
+// (precision mode MMEE_PREC_F32_SPLIT; the default attention of that mode).
+//
+// Same function as attention_f32.hip and the same arithmetic of the two contractions as attention_pair.hip
+// (LayoutLMv3SelfAttention.forward HF:235-288 + relative-position bias HF:415-457 + additive mask EE/models/LayoutLMv3.py:622-624;
+// three v_mfma_f32_32x32x16_f16 terms per product, f32 accumulate; nothing S x S of a LAYER ever in HBM).  What changes is where
+// the bias comes from.  In-kernel stamps of attention_pair.hip showed the bias phase (key metadata reads -> address arithmetic ->
+// three data-dependent LDS gathers per score and head) to be the largest single share of a wave's time (35 %), and every head of
+// every layer redid it although the three bucket indices of a (query, key) pair
+//     b1 = bucket_1d(pos_k - pos_q), bx = bucket_2d(x0_k - x0_q), by = bucket_2d(y1_k - y1_q)        (HF:392-457)
+// depend on the DOCUMENT only.  So:
+//
+//   * pair_index_kernel runs ONCE per forward: for every document it writes one 32-bit word per (query, key) pair,
+//     (4 b1) | (4 bx) << 10 | (4 by) << 20, a masked key (attention_mask == 0, or past the document in its last key tile) getting
+//     b1 = bins_1d, an extra table entry that holds -1e30.  4 B x len^2 per document (~0.9 MB), shared by all heads and all
+//     layers, stored in the register order of the score tile (lane-major) so a wave fetches a tile's 4 KB as four 1 KiB LDS-DMA
+//     pieces.  The reference materialises 2 x 4 B x heads per pair and re-reads it in every layer (HF:415-457).
+//   * the attention kernel then needs per score and head: three bit-field extracts, three lookups in the head's RAW bucket tables
+//     (33 + 64 + 64 floats: at most 2-way bank conflicts, no key metadata, no clamps) and two adds.  The sum initialises the
+//     accumulator of S^T = K Q^T (pre-multiplied by the split planes' scale), so the matrix pipe adds it to the scores.
+//   * everything else as attention_pair.hip: exp2 with the 2^10 of the split probabilities folded into the exponent, lazy
+//     rescaling (reference maximum moved only when exceeded by 2^5), K / V tiles by LDS-DMA into a double-buffered ring with ONE
+//     barrier per 32 keys, the next tile's DMA issued between the MFMAs, 3 workgroups of 4 waves per CU.
+#include <cstdlib>
+#include "mmee_common.h"
+
+namespace mmee {
+
+namespace {
+constexpr int QT = 128;        // queries per workgroup (4 waves x 32)
+constexpr int KT = 32;         // keys per tile
+constexpr int D = 64;          // head dim
+constexpr int TILE_BYTES = KT * 256;          // K (or V) tile: 32 rows x (64 hi + 64 lo) f16
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // K | V
+constexpr int BINS_MAX = 64;
+// LDS layout: bucket tables, queue slot, K / V ring
+constexpr int OFF_T1 = 0;                     // (bins1 + 1) floats (last = masked-key sentinel)
+constexpr int OFF_TX = 272;
+constexpr int OFF_TY = 528;
+constexpr int OFF_QSLOT = 784;
+constexpr int OFF_STAGE = 1024;
+constexpr int LDS_BYTES = OFF_STAGE + 2 * STAGE_BYTES;       // 33792
+constexpr int WGS = 3;
+static_assert(OFF_T1 + 4 * (BINS_MAX + 1) <= OFF_TX && OFF_TX + 4 * BINS_MAX <= OFF_TY && OFF_TY + 4 * BINS_MAX <= OFF_QSLOT, "tables");
+static_assert(WGS * LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr float kNegBig = -1.0e30f;
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kPShift = 10.0f;              // probabilities carry 2^10 into the split planes
+constexpr float kLazyLog2 = 5.0f;             // the running maximum lags by at most 2^5
+
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned img_off(int row, int ch) {     // byte offset of 16-byte chunk ch (0..15) of a tile row
+    return 256u * (unsigned)row + 16u * ((unsigned)ch ^ ((((unsigned)row & 3u) << 2) | (((unsigned)row >> 2) & 3u)));
+}
+__device__ __forceinline__ void dma16(unsigned voff, unsigned long long base, unsigned lds_addr) {
+    unsigned keep;   // m0 is saved and restored: the compiler does not accept it in a clobber list
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_addr), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned long long sgpr64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+}
+template <typename T>
+__device__ __forceinline__ T lds_load(unsigned addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>((size_t)addr);
+}
+struct HeadState {
+    f32x16 o0, o1;       // O^T accumulators: d 0..31 and 32..63 (rows) x query (lane)
+    float mref;          // reference maximum of the exponent (score domain x s_q s_k)
+    float l;             // running sum of the 2^10-scaled probabilities of this lane's keys
+};
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pair index of every document of the batch (stage-0 numbering = original document id), once per forward.
+// One workgroup per (document, 32-query block); tile (qb, kb) of a document = 1024 words at ((qb * nb + kb) * 1024) in its slab,
+// word [piece p][lane][w] <-> score register e = 4 p + w of lane (query qb*32 + (lane & 31), key kb*32 + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_index_kernel(const RowMeta* __restrict__ meta, const int* __restrict__ doc_off, int n_docs, int nb,
+                                                         const unsigned char* __restrict__ lut1, int c1, const unsigned char* __restrict__ lut2,
+                                                         int c2, int bins1, unsigned* __restrict__ out, size_t doc_stride) {
+    const int doc = blockIdx.x / nb, qb = blockIdx.x - doc * nb;
+    if (doc >= n_docs) return;
+    const int off = doc_off[doc], len = doc_off[doc + 1] - off;
+    if (qb * 32 >= len) return;
+    const int tid = threadIdx.x, lane = tid & 63, p = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int q = qb * 32 + l31;
+    const RowMeta mq = meta[off + (q < len ? q : len - 1)];
+    const int nkb = (len + 31) / 32;
+    unsigned* slab = out + (size_t)doc * doc_stride + (size_t)qb * nb * 1024;
+    for (int kb = 0; kb < nkb; ++kb) {
+        u32x4 w;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = 4 * p + t;
+            const int k = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            unsigned v;
+            if (k < len) {
+                const RowMeta mk = meta[off + k];
+                const unsigned b1 = mk.flags != 0 ? (unsigned)bins1 : (unsigned)lut1[(mk.pos - mq.pos) / 4 + c1];
+                const unsigned bx = lut2[(mk.x0 - mq.x0) / 4 + c2], by = lut2[(mk.y1 - mq.y1) / 4 + c2];
+                v = (b1 << 2) | (bx << 12) | (by << 22);
+            } else {
+                v = (unsigned)bins1 << 2;            // past the document: masked
+            }
+            w[t] = v;
+        }
+        *reinterpret_cast<u32x4*>(slab + (size_t)kb * 1024 + p * 256 + lane * 4) = w;
+    }
+}
+
+void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1,
+                       const unsigned char* lut2, int c2, int bins1, unsigned* out, size_t doc_stride, hipStream_t s) {
+    hipLaunchKernelGGL(pair_index_kernel, dim3(n_docs * nb), dim3(256), 0, s, meta, doc_off, n_docs, nb, lut1, c1, lut2, c2, bins1, out, doc_stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads; its run time means
+// nothing, the SHARES do); 2 timing variants selected by `dbg` (wrong results).  Modes 1 and 2 are never in the path.
+template <int MODE>
+__global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
+    constexpr bool DIAG = MODE == 1;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n_docs = a.counts->n_docs;
+    const int qtiles = (a.max_len + QT - 1) / QT;
+    const int n_pairs = n_docs * a.heads;
+    const size_t row_bytes = (size_t)a.ld * 4;         // a split row of Q | K | V occupies the bytes of ld floats
+    const float sc2 = a.qkv_scale * a.qkv_scale;       // score accumulators carry s_q * s_k
+    const float cexp = kLog2e / sc2;                   // exponent = acc * cexp
+    const float lazy = kLazyLog2 / cexp;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // no static LDS in this kernel: the dynamic region starts at LDS address 0, so every offset below is an instruction immediate
+    if (lds0 != 0) __builtin_trap();
+    const bool has_bias = a.pair_idx != nullptr;
+
+    int* q_slot = reinterpret_cast<int*>(smem + OFF_QSLOT);
+    const int my_xcd = a.item_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
+    int q_try = 0;
+    int item = blockIdx.x;
+    int cur_head = -1;
+    float amax = 0.f;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i, t_prev) if (DIAG) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_now = stamp_now(); __builtin_amdgcn_sched_barrier(0); ph[i] += t_now - t_prev; t_prev = t_now; }
+
+    // ---- per-lane constants of the K / V LDS-DMA: a 1 KiB piece = 4 tile rows x 256 B; lane -> (row 4 j + (lane >> 4), physical chunk
+    // lane & 15).  The logical chunk it must fetch is phys ^ swz(row), swz = ((row & 3) << 2) | ((row >> 2) & 3) = (((lane >> 4) & 3) << 2) | (j & 3);
+    // logical chunk ch = 8 plane + 2 group + half  <->  global chunk 4 group + 2 plane + half of the head's 256 contiguous bytes.
+    // For piece j the global chunk offset is g0 ^ (16 (j & 1) + 64 ((j >> 1) & 1)) with g0 the j = 0 value, and row_bytes is a multiple of
+    // 256, so the lane's whole source offset is ONE register XOR-ed with a constant per piece (nothing to keep live, nothing to spill: a
+    // spilled operand would be reloaded with a vmcnt(0) wait right in front of the DMA issue and serialise the pieces).
+    const unsigned ch0 = (unsigned)(lane & 15) ^ ((((unsigned)lane >> 4) & 3u) << 2);
+    const unsigned vdma0 = ((unsigned)lane >> 4) * (unsigned)row_bytes + 16u * (4u * ((ch0 >> 1) & 3u) + 2u * (ch0 >> 3) + (ch0 & 1u));
+    const int img = wave >> 1, pstart = (wave & 1) * 4;  // waves 0, 1 fill K (pieces 0-3, 4-7), waves 2, 3 fill V
+    // transposed-read addressing of V (constant per lane): 16-lane group g = lane >> 4 serves (h = g >> 1, d block 16 (g & 1));
+    // lane 4q + p of the group supplies row key0 + q, d = d0 + 4p .. 4p + 3.  With row0 = 4 (g >> 1) + q and dch0 = 2 (g & 1) + (p >> 1):
+    // img_off(16 ks + row0 + 8 x, dch0 + 4 dh + 8 plane) + 8 (p & 1) = (vbase ^ (32 x + 64 dh + 128 plane)) + 2048 x + 4096 ks
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+    const unsigned vbase = img_off(4 * (tg >> 1) + tq, 2 * (tg & 1) + (tp >> 1)) + 8u * (unsigned)(tp & 1);
+    // K row reads: chunk (2 st + hh) + 8 plane of row l31 = kbase ^ (32 st + 128 plane)
+    const unsigned kbase = img_off(l31, hh);
+
+    for (;; item += gridDim.x) {
+        int doc, head, qt;
+        if (a.item_counter) {
+            bool got = false;
+            while (q_try < 8) {
+                const int q = (my_xcd + q_try) & 7;
+                __syncthreads();                       // everyone has read the previous slot value
+                if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
+                __syncthreads();
+                const int j = __builtin_amdgcn_readfirstlane(*q_slot);     // wave-uniform by construction: keep doc / head / tile scalar
+                // queue q serves the documents q, q + 8, ...; within a document the order is head-major, query tile fastest: the 12-16
+                // heads of a document follow each other on ONE XCD, so its pair index (shared by all heads) is fetched into that L2 once
+                const int per_doc = a.heads * qtiles;
+                const int dl = j / per_doc;
+                const int r = j - dl * per_doc;
+                const int dq = q + 8 * dl;
+                if (dq < n_docs) {
+                    doc = dq;
+                    head = r / qtiles;
+                    qt = r - head * qtiles;
+                    got = true;
+                    break;
+                }
+                ++q_try;
+            }
+            if (!got) break;
+        } else {
+            if (item >= n_pairs * qtiles) break;
+            const int pair = item / qtiles;
+            qt = item - pair * qtiles;
+            doc = pair / a.heads;
+            head = pair - doc * a.heads;
+        }
+        const int off = a.doc_off[doc];
+        const int len = a.doc_off[doc + 1] - off;
+        const int q0 = qt * QT;
+        if (q0 >= len) continue;                       // uniform over the workgroup
+        unsigned long long tprev = 0;
+        if (DIAG) tprev = stamp_now();
+
+        __syncthreads();                               // previous item's LDS reads are done
+        if (head != cur_head && has_bias) {            // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
+            float* T1 = reinterpret_cast<float*>(smem + OFF_T1);
+            float* TX = reinterpret_cast<float*>(smem + OFF_TX);
+            float* TY = reinterpret_cast<float*>(smem + OFF_TY);
+            const float f = a.inv_sqrt_d * sc2;
+            if (tid < a.bins1) T1[tid] = a.w1[(size_t)head * a.bins1 + tid] * f;
+            if (tid == a.bins1) T1[tid] = kNegBig;
+            if (tid >= 64 && tid < 64 + a.bins2) TX[tid - 64] = a.wx[(size_t)head * a.bins2 + tid - 64] * f;
+            if (tid >= 128 && tid < 128 + a.bins2) TY[tid - 128] = a.wy[(size_t)head * a.bins2 + tid - 128] * f;
+            cur_head = head;
+        }
+
+        const int qb = (q0 >> 5) + wave;               // this wave's 32-query block of the document
+        const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
+        const bool wave_active = (q0 + wave * 32) < len;
+        const int qrow = off + (qi < len ? qi : len - 1);
+        // Q fragments (B operand of S^T = K Q^T): k-step s, element j <-> d = 16 s + 8 hh + j; split group s of the head
+        f16x8 qh[4], ql[4];
+        {
+            const char* qp = reinterpret_cast<const char*>(a.qkv) + (size_t)qrow * row_bytes + (size_t)head * 256 + 16 * hh;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qh[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s);
+                ql[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s + 32);
+            }
+        }
+
+        // ---- LDS-DMA of one key tile: K / V pieces into ring slot `buf`, this wave's pair-index tile into its private buffer ------
+        const size_t sect = (size_t)(img + 1) * (size_t)a.H * 4 + (size_t)head * 256;
+        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)off * row_bytes + sect;
+        const unsigned* idx_base = has_bias ? a.pair_idx + (size_t)a.doc_orig[doc] * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
+        auto issue_kv = [&](int kt, int buf, int jj) __attribute__((always_inline)) {      // piece jj (0..3) of this wave's share
+            if (MODE == 2 && (dbg & 4)) return;
+            if (MODE == 2 && (dbg & 16)) kt = 0;       // timing variant: every tile re-fetches the document's first rows (L2-resident source)
+            const int k0 = kt * KT;
+            const int j = pstart + jj;
+            const unsigned dst = (unsigned)OFF_STAGE + (unsigned)buf * STAGE_BYTES + (unsigned)img * TILE_BYTES + 1024u * (unsigned)j;
+            const unsigned cj = 16u * (unsigned)(j & 1) + 64u * (unsigned)((j >> 1) & 1);
+            unsigned vd = vdma0;
+            asm volatile("" : "+v"(vd));               // opaque: recomputed per piece, never a set of precomputed (spillable) registers
+            if (k0 + KT <= len) {                      // whole tile inside the document: the row goes into the scalar base
+                const unsigned long long base = (unsigned long long)(size_t)(kv_base + (size_t)(k0 + 4 * j) * row_bytes);
+                dma16(vd ^ cj, base, dst);
+            } else {                                   // last tile: rows past the document are clamped to its last row (and masked)
+                const unsigned long long base = (unsigned long long)(size_t)(kv_base + (size_t)k0 * row_bytes);
+                const int lim = len - 1 - k0;
+                const int pr = (int)((unsigned)lane >> 4);
+                int r = 4 * j + pr;
+                r = r < lim ? r : lim;
+                dma16((vd ^ cj) + (unsigned)(r - pr) * (unsigned)row_bytes, base, dst);
+            }
+        };
+        // tile kt's index words of this lane: 4 x 16 B, plain loads into registers.  They are issued at the END of tile kt - 1 (behind that
+        // tile's DMA issue) and first used after the s_waitcnt vmcnt(0) at the top of tile kt, which waits for the ring slot anyway: hipcc's own
+        // vmcnt(0) in front of the first use (it cannot count the asm DMA) therefore costs nothing.  16 registers, live across the barrier only.
+        u32x4 iw[4];
+        auto load_idx = [&](int kt) __attribute__((always_inline)) {
+            if (!has_bias || !wave_active || (MODE == 2 && (dbg & (4 | 32)))) return;      // 32: no index loads (timing variant)
+            if (MODE == 2 && (dbg & 16)) kt = 0;
+            const u32x4* p = reinterpret_cast<const u32x4*>(idx_base + (size_t)kt * 1024) + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) iw[i] = p[64 * i];
+        };
+
+        HeadState st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st.o0[e] = 0.f; st.o1[e] = 0.f; }
+        st.mref = kNegBig;
+        st.l = 0.f;
+
+        // ---- one key tile out of ring slot `buf`; the DMA of tile kt + 1 is issued between the MFMAs -----------------------------------
+        auto compute = [&](int kt, const int buf, const bool more) __attribute__((always_inline)) {
+            const unsigned sbase = (unsigned)OFF_STAGE + (unsigned)buf * STAGE_BYTES;
+            const int k0 = kt * KT;
+            if (!wave_active) {
+                if (more) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) issue_kv(kt + 1, buf ^ 1, jj);
+                }
+                return;
+            }
+            // bias = initial accumulator.  register e <-> key (e & 3) + 8 (e >> 2) + 4 hh of the tile; word e of the lane's index
+            f32x16 s;
+            if (!has_bias || (MODE == 2 && (dbg & 1))) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+                if (!has_bias && k0 + KT > len) {         // no pair index (image-only model): mask the keys past the document here
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (p == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of 24 lookups in flight, not 48: register pressure
+                    const u32x4 w = iw[p];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned v = w[t];
+                        const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
+                        const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
+                        const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
+                        s[4 * p + t] = b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
+                    }
+                }
+            }
+            STAMP(2, tprev)
+            // S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q registers).  Chunk (2 st + hh) + 8 plane of row
+            // l31 sits at kbase ^ (32 st + 128 plane): one register + one v_xor per read instead of eight address registers
+            unsigned kb = kbase;
+            asm volatile("" : "+v"(kb));                  // opaque per tile: the XORs are recomputed, not hoisted into registers
+            // fragments one k-step ahead of the MFMAs, and no further: the scheduler would otherwise hoist all eight reads (32 registers)
+            f16x8 kh = lds_load<f16x8>(sbase + kb), kl = lds_load<f16x8>(sbase + (kb ^ 128u));
+#pragma unroll
+            for (int stp = 0; stp < 4; ++stp) {
+                f16x8 khn = kh, kln = kl;
+                if (stp < 3) {
+                    khn = lds_load<f16x8>(sbase + (kb ^ (32u * (stp + 1))));
+                    kln = lds_load<f16x8>(sbase + (kb ^ (32u * (stp + 1) + 128u)));
+                }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
+                if (more) issue_kv(kt + 1, buf ^ 1, stp);    // next tile's DMA pieces ride in the shadow of the MFMAs
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                kh = khn;
+                kl = kln;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            STAMP(3, tprev)
+            if (!(MODE == 2 && (dbg & 2))) {
+                float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+                for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, s[e]), s[e + 1]);      // v_max3_f32 chain
+                tmax = fmaxf(tmax, s[15]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                if (__any(tmax > st.mref + lazy)) {                  // rare after the first tiles: move the reference, rescale
+                    const float mnew = fmaxf(st.mref, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((st.mref - mnew) * cexp);
+                    st.mref = mnew;
+                    st.l *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
+                }
+                const float negm = kPShift - st.mref * cexp;
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], cexp, negm));      // 2^10 p, p relative to the reference maximum
+                    psum += s[e];
+                }
+                st.l += psum;
+            }
+            if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
+            const unsigned Vs = sbase + TILE_BYTES;
+            unsigned vb = vbase;
+            asm volatile("" : "+v"(vb));
+            // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
+            // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ph8, pl8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 x = f32x2{s[8 * ks + j], s[8 * ks + j + 1]};
+                    const f16x2 h = __builtin_convertvector(x, f16x2);
+                    const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+                    ph8[j] = h[0]; ph8[j + 1] = h[1];
+                    pl8[j] = l[0]; pl8[j + 1] = l[1];
+                }
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vbase ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
+                    auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
+                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(Vs + (vb ^ xorc) + addc));
+                    };
+                    const h4 vh0 = trd(64u * dh, 4096u * ks);
+                    const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
+                    const h4 vl0 = trd(64u * dh + 128u, 4096u * ks);
+                    const h4 vl1 = trd(64u * dh + 128u + 32u, 4096u * ks + 2048u);
+                    f16x8 vh, vl;
+                    const f16x4 a0 = __builtin_bit_cast(f16x4, vh0), a1 = __builtin_bit_cast(f16x4, vh1);
+                    const f16x4 b0 = __builtin_bit_cast(f16x4, vl0), b1 = __builtin_bit_cast(f16x4, vl1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    if (dh == 0) {
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
+                    } else {
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // k-step 1's fragments and split are not hoisted over k-step 0 (register pressure)
+            }
+            if (more) load_idx(kt + 1);
+            STAMP(4, tprev)
+        };
+
+        const int n_kt = (len + KT - 1) / KT;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
+        load_idx(0);
+        STAMP(6, tprev)                                // item prologue: queue, tables, Q fragments, first DMA issue
+        for (int kt = 0; kt < n_kt; kt += 2) {
+            // my pieces of tile kt have landed, then the barrier: everyone's have, and everyone is done with tile kt - 1,
+            // whose ring slot the DMA issued during this tile overwrites
+            if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(0, tprev) asm volatile("s_barrier" ::: "memory"); STAMP(7, tprev) }
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            compute(kt, 0, kt + 1 < n_kt);
+            if (kt + 1 >= n_kt) break;
+            if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(0, tprev) asm volatile("s_barrier" ::: "memory"); STAMP(7, tprev) }
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            compute(kt + 1, 1, kt + 2 < n_kt);
+        }
+
+        if (wave_active) {
+            const float l_tot = st.l + __shfl_xor(st.l, 32, 64);   // the two lane halves hold disjoint keys
+            const float inv = 1.0f / (l_tot * a.qkv_scale);        // the 2^10 of the probabilities is in l as well
+            if (qi < len) {
+                char* row_split = reinterpret_cast<char*>(a.ctx) + (size_t)(off + qi) * a.ldc * 4;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
+                    f32x4 w0, w1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { w0[c] = st.o0[4 * q4 + c] * inv; w1[c] = st.o1[4 * q4 + c] * inv; }
+                    store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale, amax);
+                    store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale, amax);
+                }
+            }
+        }
+    }
+    if (a.ctx_split) split_flag_overflow(amax, a.err_flag);
+    if (DIAG && stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(stamps + i, ph[i]);
+    }
+#undef STAMP
+}
+
+static unsigned long long* g_attn_idx_stamps = nullptr;
+unsigned long long* attention_idx_stamps() { return g_attn_idx_stamps; }
+
+bool attention_idx_supports(const AttnArgs& a) {
+    return a.ctx_split && (a.pair_idx == nullptr || (a.bins1 >= 1 && a.bins1 <= BINS_MAX && a.bins2 >= 1 && a.bins2 <= BINS_MAX));
+}
+
+// a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked
+void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    // MMEE_ATTN_STAMPS=1 (diagnostic): stamped build, phase sums readable through ee_debug_attn_stamps
+    static unsigned long long* stamps = [] {
+        const char* e = getenv("MMEE_ATTN_STAMPS");
+        unsigned long long* p = nullptr;
+        if (e && e[0] == '1' && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
+        return p;
+    }();
+    static const int dbg = [] { const char* e = getenv("MMEE_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing variants (wrong results)
+    g_attn_idx_stamps = stamps;
+    const int qtiles = (a.max_len + QT - 1) / QT;
+    long items = (long)max_docs * a.heads * qtiles;
+    int grid = WGS * num_cus;
+    if (items < grid) grid = (int)items;
+    if (grid < 1) grid = 1;
+    if (stamps) hipLaunchKernelGGL(attention_idx_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0);
+    else if (dbg) hipLaunchKernelGGL(attention_idx_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg);
+    else hipLaunchKernelGGL(attention_idx_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
+}
+
+}  // namespace mmee

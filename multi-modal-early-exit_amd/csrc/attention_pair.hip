@@ -1,6 +1,6 @@
 // Fused LayoutLMv3 self-attention, split-f16 operands, TWO heads per work item (precision mode MMEE_PREC_F32_SPLIT).
 //
-// Same function as attention_split.hip (LayoutLMv3SelfAttention.forward HF:235-288 + the relative-position bias of HF:415-457 +
+// Same function as attention_f32.hip (LayoutLMv3SelfAttention.forward HF:235-288 + the relative-position bias of HF:415-457 +
 // the additive mask of EE/models/LayoutLMv3.py:622-624; nothing S x S in HBM, online softmax, one query per lane) and the same
 // arithmetic of the two contractions (three v_mfma_f32_32x32x16_f16 terms per product, f32 accumulate).  What changes is
 // everything around the MFMAs, which is what rocprof showed the one-head kernel to be bound by (LDS 51 % busy of which a third

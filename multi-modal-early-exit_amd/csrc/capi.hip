@@ -68,6 +68,10 @@ struct ee_handle {
     float *Xs = nullptr, *Ys = nullptr;           // split-f16 copies of X / Y rows (MMEE_PREC_F32_SPLIT)
     float* absmax_dev = nullptr;
     bool split = false;
+    unsigned* pair_idx = nullptr;                 // split mode, LayoutLMv3: one word per (query, key) pair of every document (attention_idx.hip)
+    unsigned char *lut1_dev = nullptr, *lut2_dev = nullptr;
+    int idx_nb = 0;
+    size_t idx_stride = 0;
     float* cls_f32 = nullptr;                     // split mode: CLS rows of the active documents rebuilt from the split planes
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
     int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
@@ -281,6 +285,13 @@ int ee_create(const ee_config* c, ee_handle** out) {
             return fail(nullptr, "MMEE_PREC_F32_SPLIT: max_docs * rows per document * hidden_size * 4 must stay below 4 GiB (got %.2f GiB); "
                                  "use a smaller max_docs per handle", x_bytes / 1073741824.0);
     }
+    if (c->precision == MMEE_PREC_F32_SPLIT && !beit && !(c->rel_pos_bins <= 64 && c->rel_2d_pos_bins <= 64) &&
+        !(c->max_rel_pos <= 128 && c->max_rel_2d_pos <= 256))
+        return fail(nullptr, "MMEE_PREC_F32_SPLIT: the split-precision attention kernels hold bucket tables of <= 64 bins (attention_idx) or "
+                             "distances <= 128 / 256 (attention_pair); got bins %d / %d, distances %d / %d: use MMEE_PREC_F32",
+                    c->rel_pos_bins, c->rel_2d_pos_bins, c->max_rel_pos, c->max_rel_2d_pos);
+    if (c->precision == MMEE_PREC_F32_SPLIT && (c->num_attention_heads < 1 || c->rel_pos_bins < 2 || c->rel_2d_pos_bins < 2) && !beit)
+        return fail(nullptr, "bad relative-position configuration");
     if (c->exit_head_num_layers != 1 && c->exit_head_num_layers != 2) return fail(nullptr, "exit_head_num_layers must be 1 or 2");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -419,6 +430,11 @@ int ee_create(const ee_config* c, ee_handle** out) {
             rc |= dev_alloc(h, &h->Ys, rows * H);
             rc |= dev_alloc(h, &h->absmax_dev, 4);
             rc |= dev_alloc(h, &h->cls_f32, Bm * H);
+            if (!beit) {
+                h->idx_nb = (int)((Tm + Pv + 31) / 32);
+                h->idx_stride = (size_t)h->idx_nb * h->idx_nb * 1024;
+                rc |= dev_alloc(h, &h->pair_idx, Bm * h->idx_stride);
+            }
         }
         rc |= dev_alloc(h, &h->vis_raw, Bm * NP * H);
         rc |= dev_alloc(h, &h->text_part, Bm * tch * H);
@@ -596,17 +612,17 @@ int ee_finalize(ee_handle* h) {
     std::vector<unsigned char> l1(h->n1), l2(h->n2);
     bucket_lut_host(c.rel_pos_bins, c.max_rel_pos, h->c1, l1.data());
     bucket_lut_host(c.rel_2d_pos_bins, c.max_rel_2d_pos, h->c2, l2.data());
-    unsigned char *d1 = nullptr, *d2 = nullptr;
-    HIP_OK(h, hipMalloc((void**)&d1, h->n1));
-    HIP_OK(h, hipMalloc((void**)&d2, h->n2));
+    if (!h->lut1_dev) {
+        if (dev_alloc(h, &h->lut1_dev, (size_t)h->n1)) return 1;
+        if (dev_alloc(h, &h->lut2_dev, (size_t)h->n2)) return 1;
+    }
+    unsigned char *d1 = h->lut1_dev, *d2 = h->lut2_dev;      // kept: the per-forward pair index is built from them
     HIP_OK(h, hipMemcpy(d1, l1.data(), h->n1, hipMemcpyHostToDevice));
     HIP_OK(h, hipMemcpy(d2, l2.data(), h->n2, hipMemcpyHostToDevice));
     launch_build_value_tables(h->rel1, h->relx, h->rely, d1, d2, c.num_attention_heads, c.rel_pos_bins, c.rel_2d_pos_bins,
                               h->n1, h->n2, 1.0f / std::sqrt((float)(c.hidden_size / c.num_attention_heads)), h->t1, h->tx,
                               h->ty, nullptr);
     HIP_OK(h, hipDeviceSynchronize());
-    (void)hipFree(d1);
-    (void)hipFree(d2);
     h->finalized = true;
     return 0;
 }
@@ -666,6 +682,10 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         return p;
     };
     if (h->prof_on) { h->prof_recs.clear(); h->prof_used = 0; }
+    // split precision attention: attention_idx.hip (pair index built once per forward; default) or, with MMEE_ATTN_V=2 or bucket tables
+    // beyond 64 bins, attention_pair.hip (clamped Delta tables gathered per layer and head)
+    static const int attn_v = [] { const char* e = getenv("MMEE_ATTN_V"); return e ? atoi(e) : 0; }();
+    const bool use_idx = h->split && attn_v == 0 && c.rel_pos_bins <= 64 && c.rel_2d_pos_bins <= 64;
     bool need[3] = {false, false, false};
     for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
 
@@ -693,7 +713,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     pa.text_dst = h->text_dst; pa.emb_pos = h->emb_pos; pa.ntext = h->ntext;
     pa.doc_off = S_doc_off(0); pa.x_src = S_x_src(0); pa.doc_orig = S_doc_orig(0);
     pa.meta = h->meta[0]; pa.counts = h->counts; pa.err_flag = h->err_flag;
-    { ProfScope ps(h, P_PREP, s); launch_prep(pa, s); }
+    {
+        ProfScope ps(h, P_PREP, s);
+        launch_prep(pa, s);
+        if (h->pair_idx && use_idx)      // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
+            mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->lut2_dev, h->c2, c.rel_pos_bins,
+                                    h->pair_idx, h->idx_stride, s);
+    }
 
     // ---- embeddings --------------------------------------------------------------------------------------------
     EmbedArgs ea{};
@@ -734,9 +760,6 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     const bool sp = h->split;
     if (sp && !beit)     // the first QKV projection reads split-f16 rows; later layers get them from the LayerNorm kernel
         mmee::launch_split_rows(h->X, h->Xs, &h->counts[0].n_rows, 0, max_rows, H, mmee::kSplitScaleX, cus, s, h->err_flag);
-    // split precision: two heads per work item (attention_pair.hip) unless MMEE_ATTN_V=1 asks for the one-head kernel (A/B switch)
-    static const bool force_v1 = [] { const char* e = getenv("MMEE_ATTN_V"); return e && e[0] == '1'; }();
-    auto use_pair = [&](const AttnArgs& at) { return !force_v1 && mmee::attention_pair_supports(at, c.max_rel_pos, c.max_rel_2d_pos); };
     auto run_gemm = [&](const GemmArgs& g, int epi) {
         if (sp) launch_gemm_split(g, epi, max_rows, cus, s);
         else launch_gemm_f32(g, epi, AMODE_ROWS, max_rows, cus, s);
@@ -744,6 +767,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
 
     // ---- exit stages ---------------------------------------------------------------------------------------------
     int cur = 0, meta_cur = 0, exit_index = 0;
+    auto fill_idx = [&](AttnArgs& at) {
+        at.pair_idx = (use_idx && !beit) ? h->pair_idx : nullptr;
+        at.idx_doc_stride = h->idx_stride; at.idx_nb = h->idx_nb; at.doc_orig = S_doc_orig(cur);
+        at.w1 = h->rel1; at.wx = h->relx; at.wy = h->rely; at.bins1 = c.rel_pos_bins; at.bins2 = c.rel_2d_pos_bins;
+        at.inv_sqrt_d = 1.0f / std::sqrt((float)(H / c.num_attention_heads));
+    };
     const int* x_phys = S_x_src(0);
     bool use_row_src = false;
     h->layer_stage.assign(L, 0);
@@ -835,7 +864,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
             at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
             at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
-            { ProfScope ps(h, P_ATTN, s); if (sp && use_pair(at)) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
+            fill_idx(at);
+        { ProfScope ps(h, P_ATTN, s); if (sp && use_idx && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s); else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else launch_attention_f32(at, B, cus, s); }
             g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
             g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
@@ -864,7 +894,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
         at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
         at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
-        { ProfScope ps(h, P_ATTN, s); if (sp && use_pair(at)) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else if (sp) launch_attention_split(at, B, cus, s); else launch_attention_f32(at, B, cus, s); }
+        fill_idx(at);
+        { ProfScope ps(h, P_ATTN, s); if (sp && use_idx && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s); else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else launch_attention_f32(at, B, cus, s); }
         // attention output dense + residual (HF:299-303), then LayerNorm
         g = GemmArgs{};
         g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = rs;
@@ -1103,7 +1134,7 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
 }
 
 int ee_debug_attn_stamps(uint64_t* out8) {
-    unsigned long long* d = mmee::attention_pair_stamps();
+    unsigned long long* d = mmee::attention_idx_stamps() ? mmee::attention_idx_stamps() : mmee::attention_pair_stamps();
     if (!out8 || !d) return fail(nullptr, "ee_debug_attn_stamps: no stamped launch has run (set MMEE_ATTN_STAMPS=1 before the first forward)");
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out8, d, 64, hipMemcpyDeviceToHost) != hipSuccess)
         return fail(nullptr, "ee_debug_attn_stamps: copy failed");

@@ -245,8 +245,16 @@ struct AttnArgs {
     int* item_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
     int ctx_split;
     float ctx_scale;
-    float qkv_scale;                 // attention_split.hip: scale of the split Q | K | V rows (qkv then points to split rows)
+    float qkv_scale;                 // split-precision attention: scale of the split Q | K | V rows (qkv then points to split rows)
     int* err_flag;                   // ctx_split: kErrSplitOverflow when a context value had to be clamped; may be null
+    // attention_idx.hip: per-document pair index (one word per (query, key) pair, built once per forward) + the raw bucket tables
+    const unsigned* pair_idx;        // null: no relative-position bias (image-only model)
+    size_t idx_doc_stride;           // words per document slab = idx_nb * idx_nb * 1024
+    int idx_nb;                      // 32-row blocks per side of a slab
+    const int* doc_orig;             // [n_docs] original document id of the active stage's documents (slab index)
+    const float *w1, *wx, *wy;       // rel_pos_bias / rel_pos_x_bias / rel_pos_y_bias weights, [heads][bins]
+    int bins1, bins2;
+    float inv_sqrt_d;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -260,8 +268,12 @@ void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n
                        int num_cus, hipStream_t s, int* err_flag = nullptr);
 void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
-void launch_attention_split(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 unsigned long long* attention_pair_stamps();
+unsigned long long* attention_idx_stamps();
+bool attention_idx_supports(const AttnArgs& a);
+void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
+void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1,
+                       const unsigned char* lut2, int c2, int bins1, unsigned* out, size_t doc_stride, hipStream_t s);
 bool attention_pair_supports(const AttnArgs& a, int max_rel_pos, int max_rel_2d_pos);
 void launch_attention_pair(const AttnArgs& a, int max_docs, int num_cus, int max_rel_pos, int max_rel_2d_pos, int any_masked, hipStream_t s);
 size_t gemm_f32_lds_bytes();
