@@ -39,10 +39,8 @@ constexpr int OFF_TX = 272;
 constexpr int OFF_TY = 528;
 constexpr int OFF_QSLOT = 784;
 constexpr int OFF_STAGE = 1024;
-constexpr int LDS_BYTES = OFF_STAGE + 2 * STAGE_BYTES;       // 33792
 constexpr int WGS = 3;
 static_assert(OFF_T1 + 4 * (BINS_MAX + 1) <= OFF_TX && OFF_TX + 4 * BINS_MAX <= OFF_TY && OFF_TY + 4 * BINS_MAX <= OFF_QSLOT, "tables");
-static_assert(WGS * LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr float kNegBig = -1.0e30f;
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kPShift = 10.0f;              // probabilities carry 2^10 into the split planes
@@ -127,7 +125,12 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 // ---------------------------------------------------------------------------------------------------------------
 // MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads; its run time means
 // nothing, the SHARES do); 2 timing variants selected by `dbg` (wrong results).  Modes 1 and 2 are never in the path.
-template <int MODE>
+// RING = ring depth of the K / V stages.  2: the next tile's DMA is issued during a tile and waited for (vmcnt(0)) at the top of the next; the
+// pair-index words are plain loads issued at the end of the previous tile.  3: the DMA of tile kt + 2 is issued during tile kt, every wait is
+// COUNTED (a tile never waits for a DMA it does not need yet), and the index words are asm loads issued right behind the barrier and consumed
+// after the Q K^T MFMAs of the same tile (the bias is then added to the finished scores instead of initialising the accumulator): no
+// compiler-visible vector load is in flight beside the DMA, whose completion hipcc would otherwise wait for at the load's first use.
+template <int MODE, int RING>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             cur_head = head;
         }
 
+        const int slab = has_bias ? __builtin_amdgcn_readfirstlane(a.doc_orig[doc]) : 0;      // fetched before the counted regime starts
         const int qb = (q0 >> 5) + wave;               // this wave's 32-query block of the document
         const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
         const bool wave_active = (q0 + wave * 32) < len;
@@ -232,17 +236,30 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         f16x8 qh[4], ql[4];
         {
             const char* qp = reinterpret_cast<const char*>(a.qkv) + (size_t)qrow * row_bytes + (size_t)head * 256 + 16 * hh;
+            if constexpr (RING == 3) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table fill / previous item's stores: done before the counted regime starts
+                // asm loads: from here to the end of the item only hand-counted vector memory operations are in flight.  They are older than
+                // the first tiles' DMA pieces issued below, so the counted wait at the top of tile 0 covers them; no wait of their own.
+                asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
+                             "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
+                             "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
+                             "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224"
+                             : "=&v"(qh[0]), "=&v"(ql[0]), "=&v"(qh[1]), "=&v"(ql[1]), "=&v"(qh[2]), "=&v"(ql[2]), "=&v"(qh[3]), "=&v"(ql[3])
+                             : "v"(qp)
+                             : "memory");
+            } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                qh[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s);
-                ql[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s + 32);
+                for (int s = 0; s < 4; ++s) {
+                    qh[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s);
+                    ql[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s + 32);
+                }
             }
         }
 
         // ---- LDS-DMA of one key tile: K / V pieces into ring slot `buf`, this wave's pair-index tile into its private buffer ------
         const size_t sect = (size_t)(img + 1) * (size_t)a.H * 4 + (size_t)head * 256;
         const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)off * row_bytes + sect;
-        const unsigned* idx_base = has_bias ? a.pair_idx + (size_t)a.doc_orig[doc] * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
+        const unsigned* idx_base = has_bias ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
         auto issue_kv = [&](int kt, int buf, int jj) __attribute__((always_inline)) {      // piece jj (0..3) of this wave's share
             if (MODE == 2 && (dbg & 4)) return;
             if (MODE == 2 && (dbg & 16)) kt = 0;       // timing variant: every tile re-fetches the document's first rows (L2-resident source)
@@ -281,6 +298,76 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         for (int e = 0; e < 16; ++e) { st.o0[e] = 0.f; st.o1[e] = 0.f; }
         st.mref = kNegBig;
         st.l = 0.f;
+
+        // ---- softmax (lazy rescaling, 2^10 folded into the exponent) + O^T += V^T P^T on a finished score tile; Vs = LDS address of the V tile ----
+        auto softmax_pv = [&](f32x16& s, HeadState& st, const unsigned Vs) __attribute__((always_inline)) {
+            if (!(MODE == 2 && (dbg & 2))) {
+                float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+                for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, s[e]), s[e + 1]);      // v_max3_f32 chain
+                tmax = fmaxf(tmax, s[15]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                if (__any(tmax > st.mref + lazy)) {                  // rare after the first tiles: move the reference, rescale
+                    const float mnew = fmaxf(st.mref, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((st.mref - mnew) * cexp);
+                    st.mref = mnew;
+                    st.l *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
+                }
+                const float negm = kPShift - st.mref * cexp;
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], cexp, negm));      // 2^10 p, p relative to the reference maximum
+                    psum += s[e];
+                }
+                st.l += psum;
+            }
+            if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
+            unsigned vb = vbase;
+            asm volatile("" : "+v"(vb));
+            // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
+            // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ph8, pl8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 x = f32x2{s[8 * ks + j], s[8 * ks + j + 1]};
+                    const f16x2 h = __builtin_convertvector(x, f16x2);
+                    const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+                    ph8[j] = h[0]; ph8[j + 1] = h[1];
+                    pl8[j] = l[0]; pl8[j + 1] = l[1];
+                }
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vbase ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
+                    auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
+                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(Vs + (vb ^ xorc) + addc));
+                    };
+                    const h4 vh0 = trd(64u * dh, 4096u * ks);
+                    const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
+                    const h4 vl0 = trd(64u * dh + 128u, 4096u * ks);
+                    const h4 vl1 = trd(64u * dh + 128u + 32u, 4096u * ks + 2048u);
+                    f16x8 vh, vl;
+                    const f16x4 a0 = __builtin_bit_cast(f16x4, vh0), a1 = __builtin_bit_cast(f16x4, vh1);
+                    const f16x4 b0 = __builtin_bit_cast(f16x4, vl0), b1 = __builtin_bit_cast(f16x4, vl1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                    if (dh == 0) {
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
+                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
+                    } else {
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
+                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);        // k-step 1's fragments and split are not hoisted over k-step 0 (register pressure)
+            }
+        };
 
         // ---- one key tile out of ring slot `buf`; the DMA of tile kt + 1 is issued between the MFMAs -----------------------------------
         auto compute = [&](int kt, const int buf, const bool more) __attribute__((always_inline)) {
@@ -340,78 +427,111 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(3, tprev)
-            if (!(MODE == 2 && (dbg & 2))) {
-                float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-                for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, s[e]), s[e + 1]);      // v_max3_f32 chain
-                tmax = fmaxf(tmax, s[15]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                if (__any(tmax > st.mref + lazy)) {                  // rare after the first tiles: move the reference, rescale
-                    const float mnew = fmaxf(st.mref, tmax);
-                    const float alpha = __builtin_amdgcn_exp2f((st.mref - mnew) * cexp);
-                    st.mref = mnew;
-                    st.l *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
-                }
-                const float negm = kPShift - st.mref * cexp;
-                float psum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], cexp, negm));      // 2^10 p, p relative to the reference maximum
-                    psum += s[e];
-                }
-                st.l += psum;
-            }
-            if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
-            const unsigned Vs = sbase + TILE_BYTES;
-            unsigned vb = vbase;
-            asm volatile("" : "+v"(vb));
-            // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
-            // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 ph8, pl8;
-#pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const f32x2 x = f32x2{s[8 * ks + j], s[8 * ks + j + 1]};
-                    const f16x2 h = __builtin_convertvector(x, f16x2);
-                    const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
-                    ph8[j] = h[0]; ph8[j + 1] = h[1];
-                    pl8[j] = l[0]; pl8[j + 1] = l[1];
-                }
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh) {
-                    // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vbase ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
-                    auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
-                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(Vs + (vb ^ xorc) + addc));
-                    };
-                    const h4 vh0 = trd(64u * dh, 4096u * ks);
-                    const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
-                    const h4 vl0 = trd(64u * dh + 128u, 4096u * ks);
-                    const h4 vl1 = trd(64u * dh + 128u + 32u, 4096u * ks + 2048u);
-                    f16x8 vh, vl;
-                    const f16x4 a0 = __builtin_bit_cast(f16x4, vh0), a1 = __builtin_bit_cast(f16x4, vh1);
-                    const f16x4 b0 = __builtin_bit_cast(f16x4, vl0), b1 = __builtin_bit_cast(f16x4, vl1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
-                    if (dh == 0) {
-                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
-                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
-                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
-                    } else {
-                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
-                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
-                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);        // k-step 1's fragments and split are not hoisted over k-step 0 (register pressure)
-            }
+            softmax_pv(s, st, sbase + TILE_BYTES);
             if (more) load_idx(kt + 1);
             STAMP(4, tprev)
         };
 
         const int n_kt = (len + KT - 1) / KT;
+        if constexpr (RING == 3) {
+            // ---- 3-deep ring, counted waits ----------------------------------------------------------------------------------------------
+            const unsigned long long ib0 = (unsigned long long)(size_t)idx_base;
+            const unsigned ivoff = 16u * (unsigned)lane;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
+            if (n_kt > 1) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) issue_kv(1, 1, jj);
+            }
+            STAMP(6, tprev)
+            int slot = 0;
+            for (int kt = 0; kt < n_kt; ++kt) {
+                const bool more1 = kt + 1 < n_kt, more2 = kt + 2 < n_kt;
+                // tile kt has landed: everything but the (up to) four youngest operations = the pieces of tile kt + 1 is complete; then the
+                // barrier: everyone's pieces have, and everyone is done with tile kt - 1, whose slot tile kt + 2 goes into
+                if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP(0, tprev)
+                // this tile's index words: asm loads issued in front of the barrier (its wait covers part of their latency) and BEFORE the DMA
+                // pieces of tile kt + 2, so that the counted wait behind the Q K^T MFMAs covers them
+                u32x4 iw0, iw1, iw2, iw3;
+                const bool want_idx = wave_active && has_bias && !(MODE == 2 && (dbg & (1 | 32)));
+                if (want_idx) {
+                    const unsigned long long ib = sgpr64(ib0 + (unsigned long long)kt * 4096ull);
+                    // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
+                    // states, and nothing inside an asm string is padded by the compiler)
+                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                                 : "=&v"(iw0), "=&v"(iw1), "=&v"(iw2), "=&v"(iw3)
+                                 : "v"(ivoff), "s"(ib)
+                                 : "memory");
+                }
+                asm volatile("s_barrier" ::: "memory");
+                STAMP(7, tprev)
+                const int slot2 = slot == 0 ? 2 : slot - 1;       // (slot + 2) % 3
+                if (!wave_active) {
+                    if (more2) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) issue_kv(kt + 2, slot2, jj);
+                    }
+                    slot = slot == 2 ? 0 : slot + 1;
+                    continue;
+                }
+                const int k0 = kt * KT;
+                const unsigned sbase = (unsigned)OFF_STAGE + (unsigned)slot * STAGE_BYTES;
+                // S^T = K Q^T from a zero accumulator; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them.
+                // (kbase + sbase) ^ c == (kbase ^ c) + sbase: c touches bits 5-7, sbase bits >= 10
+                f32x16 s;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+                const unsigned kb = kbase + sbase;
+                f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
+#pragma unroll
+                for (int stp = 0; stp < 4; ++stp) {
+                    f16x8 khn = kh, kln = kl;
+                    if (stp < 3) {
+                        khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
+                        kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
+                    }
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
+                    if (more2) issue_kv(kt + 2, slot2, stp);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                    kh = khn;
+                    kl = kln;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                STAMP(3, tprev)
+                // bias: the index words are back when all but the pieces issued above are (they are older than those)
+                if (want_idx) {
+                    // wait-only statements WITHOUT operands: naming the index registers here lets the register allocator copy them in front
+                    // of the wait (seen in the .s: v_mov of words that had not landed).  The sched_barrier keeps their first use below it.
+                    if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        if (p == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const unsigned v = iw[p][t];
+                            const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
+                            const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
+                            const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
+                            s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
+                        }
+                    }
+                } else if (!has_bias && k0 + KT > len) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : s[e];
+                }
+                STAMP(2, tprev)
+                softmax_pv(s, st, sbase + TILE_BYTES);
+                STAMP(4, tprev)
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
         load_idx(0);
@@ -426,6 +546,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(0, tprev) asm volatile("s_barrier" ::: "memory"); STAMP(7, tprev) }
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             compute(kt + 1, 1, kt + 2 < n_kt);
+        }
         }
 
         if (wave_active) {
@@ -460,14 +581,30 @@ bool attention_idx_supports(const AttnArgs& a) {
 }
 
 // a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked
-void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
+template <int RING>
+static void launch_idx_ring(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
+    constexpr int lds = OFF_STAGE + RING * STAGE_BYTES;
+    static_assert(WGS * lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
+    const int qtiles = (a.max_len + QT - 1) / QT;
+    long items = (long)max_docs * a.heads * qtiles;
+    int grid = WGS * num_cus;
+    if (items < grid) grid = (int)items;
+    if (grid < 1) grid = 1;
+    if (stamps) hipLaunchKernelGGL((attention_idx_kernel<1, RING>), dim3(grid), dim3(256), lds, s, a, stamps, 0);
+    else if (dbg) hipLaunchKernelGGL((attention_idx_kernel<2, RING>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, dbg);
+    else hipLaunchKernelGGL((attention_idx_kernel<0, RING>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, 0);
+}
+
+// a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
+// MMEE_ATTN_RING=2 selects the double-buffered form (A/B switch); default: 3-deep ring with counted waits.
+void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
     // MMEE_ATTN_STAMPS=1 (diagnostic): stamped build, phase sums readable through ee_debug_attn_stamps
     static unsigned long long* stamps = [] {
         const char* e = getenv("MMEE_ATTN_STAMPS");
@@ -476,15 +613,10 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         return p;
     }();
     static const int dbg = [] { const char* e = getenv("MMEE_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing variants (wrong results)
+    static const int ring = [] { const char* e = getenv("MMEE_ATTN_RING"); return (e && e[0] == '2') ? 2 : 3; }();
     g_attn_idx_stamps = stamps;
-    const int qtiles = (a.max_len + QT - 1) / QT;
-    long items = (long)max_docs * a.heads * qtiles;
-    int grid = WGS * num_cus;
-    if (items < grid) grid = (int)items;
-    if (grid < 1) grid = 1;
-    if (stamps) hipLaunchKernelGGL(attention_idx_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0);
-    else if (dbg) hipLaunchKernelGGL(attention_idx_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg);
-    else hipLaunchKernelGGL(attention_idx_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
+    if (ring == 3) launch_idx_ring<3>(a, max_docs, num_cus, stamps, dbg, s);
+    else launch_idx_ring<2>(a, max_docs, num_cus, stamps, dbg, s);
 }
 
 }  // namespace mmee

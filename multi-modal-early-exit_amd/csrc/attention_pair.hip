@@ -67,8 +67,9 @@ __device__ __forceinline__ unsigned img_off(int row, int ch) {     // byte offse
 }
 
 __device__ __forceinline__ void dma16(unsigned voff, unsigned long long base, unsigned lds_addr) {
-    unsigned keep;   // m0 is saved and restored: the compiler does not accept it in a clobber list
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+    unsigned keep;   // m0 is saved and restored: the compiler does not accept it in a clobber list.  s_nop 3: the scalar base may come straight
+    // from v_readfirstlane (VALU write of an SGPR -> VMEM read: 5 wait states; the two s_mov count)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(lds_addr), "s"(base)
                  : "memory");
