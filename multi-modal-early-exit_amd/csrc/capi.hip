@@ -99,6 +99,7 @@ struct ee_handle {
     std::vector<int> layer_stage;
     std::vector<int> exit_stage;
     uint32_t last_flags = 0;
+    bool last_gate_heads = true;                  // gate strategy: were the 2-way gate heads evaluated in the last forward
 };
 
 namespace {
@@ -805,9 +806,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             run_head(h->classifier, in, ld, gather, h->hid, h->pol_logits);
             pol = h->pol_logits;
         } else if (c.strategy == MMEE_STRATEGY_GATE) {
-            run_head(*hw, in, ld, gather, h->hid, h->head_logits);            // 2-way gate logits (exit_states)
+            // the policy only ever sees classifier(gate input) (EE/utils.py:183-188); the 2-way gate logits (exit_states) are
+            // computed when the caller asked for them (the dump of model.forward), not in the fast path
+            const bool want_gate = out_head_logits || out_head_crit;
+            if (want_gate) run_head(*hw, in, ld, gather, h->hid, h->head_logits);
             run_head(h->classifier, in, ld, gather, h->hid2, h->pol_logits);  // gated_logits, EE/models/LayoutLMv3.py:768
-            pol = h->pol_logits; head = h->head_logits; Kh = head_dim_out;
+            pol = h->pol_logits; head = want_gate ? h->head_logits : nullptr; Kh = head_dim_out;
         } else {
             run_head(*hw, in, ld, gather, h->hid, h->head_logits);
             pol = h->head_logits; head = h->head_logits; Kh = K;
@@ -948,6 +952,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         run_exit(nullptr, h->X, H, x_phys, true);
     }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
+    h->last_gate_heads = out_head_logits || out_head_crit;
     HIP_OK(h, hipMemcpyAsync(h->err_host, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipEventRecord(h->fwd_done, s));
     h->last_stream = s; h->has_fwd = true;
@@ -996,8 +1001,9 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
         const double n = sc[h->exit_stage[e]].n_docs;
         const bool fin = e == E;
         const double dense = (fin || c.exit_head_num_layers == 2) ? 2.0 * H * H : 0.0;
-        gf += n * (dense + 2.0 * H * (fin ? c.num_labels : ko));
-        if (!fin && c.strategy == MMEE_STRATEGY_GATE) gf += n * (2.0 * H * H + 2.0 * H * c.num_labels);
+        const bool gate = !fin && c.strategy == MMEE_STRATEGY_GATE;
+        if (!gate || h->last_gate_heads) gf += n * (dense + 2.0 * H * (fin ? c.num_labels : ko));
+        if (gate) gf += n * (2.0 * H * H + 2.0 * H * c.num_labels);
     }
     if (gemm_flops) *gemm_flops = gf;
     if (attn_flops) *attn_flops = af;
