@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
     const float lazy = kLazyLog2 / cexp;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // no static LDS in this kernel: the dynamic region starts at LDS address 0, so every offset below is an instruction immediate
-    if (lds0 != 0) __builtin_trap();
+    if (lds0 != 0) {                            // would be a toolchain change; reported through err_flag (bit 32), nothing is computed
+        if (threadIdx.x == 0 && a.err_flag) atomicOr(a.err_flag, 32);
+        return;
+    }
     const bool has_bias = a.pair_idx != nullptr;
 
     int* q_slot = reinterpret_cast<int*>(smem + OFF_QSLOT);

@@ -127,8 +127,11 @@ __global__ __launch_bounds__(256, Lds<HP>::WGS) void attention_pair_kernel(const
     const float lazy = kLazyLog2 / cexp;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // The kernel declares no static LDS, so the dynamic region starts at LDS address 0 and every table / ring offset below is an
-    // instruction immediate instead of a register (checked here: a toolchain that breaks the assumption traps instead of gathering garbage)
-    if (lds0 != 0) __builtin_trap();
+    // instruction immediate instead of a register (checked here: a toolchain that breaks the assumption is reported, nothing is gathered)
+    if (lds0 != 0) {                            // would be a toolchain change; reported through err_flag (bit 32), nothing is computed
+        if (threadIdx.x == 0 && a.err_flag) atomicOr(a.err_flag, 32);
+        return;
+    }
     // table entry of a key: index = med3(key - query + R, 0, 2 R) (one v_med3_i32: inline 0, scalar bound), byte offset = ENT * index
     const int hi1 = 2 * ENT * r1, hi2 = 2 * ENT * r2;
 

@@ -973,6 +973,8 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
         if (docs_out) docs_out[i] = sc[h->exit_stage[i]].n_docs;
         if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
     }
+    if (err & 32)
+        return fail(h, "ee_forward: internal error (flags %d): the attention kernel found its dynamic LDS region away from address 0", err);
     if (err & mmee::kErrSplitOverflow)
         return fail(h, "ee_forward: split-precision overflow (flags %d): an activation left the range of the split-f16 planes (|LayerNorm out|, "
                        "|Q/sqrt(d)|, |K|, |V|, |GELU out| <= 3750, |attention context| <= 937) and was clamped, so the result is WRONG; "
