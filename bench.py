@@ -316,13 +316,12 @@ def main():
         eng.profile(False)
         c = eng.stage_counts()
         H, I = cfg.hidden_size, cfg.intermediate_size
-        stage_of_layer, s = [], 0
-        for l in range(cfg.num_hidden_layers):
-            stage_of_layer.append(s)
-            if (l + 1) in EXIT_LAYERS:
-                s += 1
-        rows = [c["rows"][st] for st in stage_of_layer]
+        # rows each layer's FFN-up launch ran on.  Exit layers decide first (CLS probe) and run their bulk on the rows that stay;
+        # the last layer is the probe alone.  The probes' own small launches are a separate role (cls_probe), not in this figure.
+        plan = eng.layer_plan()
+        rows = [r for r in plan["rows_main"] if r > 0]
         up_flops = sum(2.0 * r * H * I for r in rows)                  # algorithmic FLOPs of the FFN-up launches
+        line["layer_plan_last_step_rank0"] = {k: plan[k] for k in ("rows_qkv", "rows_main", "docs_probe")}
         up = prof["gemm_ffn_up"]
         gemm_ms = sum(prof[k]["ms"] for k in ("gemm_qkv", "gemm_attn_out", "gemm_ffn_up", "gemm_ffn_down", "gemm_patch"))
         ach = up_flops / (up["ms"] * 1e-3) / 1e12
@@ -344,7 +343,7 @@ def main():
         fl2 = eng.flops()
         if world == 1 and not a.no_traffic:
             # kernel-name fragments of the FFN-up launches as rocprofv3 prints them
-            ksub = "16>, 1, true, false>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output
+            ksub = "16>, 1, true, false, 0>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output
             tb, detail = measure_hbm_traffic(thr, B, ksub, eng.precision)
             line["roofline"]["traffic"] = tb
             line["roofline"]["traffic_detail"] = detail

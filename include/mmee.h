@@ -144,6 +144,14 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
                          void* stream);
 /* FLOPs (2*M*N*K counting) the GEMM and attention kernels of the last ee_forward executed (synchronises). */
 int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* stream);
+/* How the last ee_forward ran each encoder layer (synchronises).  A layer that ends in a decision (an exit head, or the final
+ * classifier) is run "probe first" in split precision: Q|K|V for every row of the stage, then the layer's output for the CLS row of
+ * every document only (the one row the head reads, EE/models/LayoutLMv3.py:757-768), the decision, and the rest of the layer for
+ * the documents that stay.  Per layer l < cap: rows whose Q|K|V was projected, rows the attention / attention-out / FFN ran on
+ * (0: none, the last layer), documents probed (0: the layer was run whole).  probe_flops: FLOPs of all the probes, which
+ * ee_last_flops leaves out. */
+int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int32_t* docs_probe, int32_t cap, double* probe_flops,
+                       void* stream);
 
 /*
  * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]

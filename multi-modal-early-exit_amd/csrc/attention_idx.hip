@@ -210,10 +210,12 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             doc = pair / a.heads;
             head = pair - doc * a.heads;
         }
-        const int off = a.doc_off[doc];
+        const int off = a.doc_off[doc];                // context rows are written in the current numbering,
+        const int qoff = a.qkv_doc_off ? a.qkv_doc_off[doc] : off;      // Q | K | V rows may still be in the previous stage's (probe-first layers)
         const int len = a.doc_off[doc + 1] - off;
+        const int qlen = a.q_limit > 0 && a.q_limit < len ? a.q_limit : len;      // queries wanted (CLS probe: the first block only)
         const int q0 = qt * QT;
-        if (q0 >= len) continue;                       // uniform over the workgroup
+        if (q0 >= qlen) continue;                      // uniform over the workgroup
         unsigned long long tprev = 0;
         if (DIAG) tprev = stamp_now();
 
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         const int slab = has_bias ? __builtin_amdgcn_readfirstlane(a.doc_orig[doc]) : 0;      // fetched before the counted regime starts
         const int qb = (q0 >> 5) + wave;               // this wave's 32-query block of the document
         const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
-        const bool wave_active = (q0 + wave * 32) < len;
-        const int qrow = off + (qi < len ? qi : len - 1);
+        const bool wave_active = (q0 + wave * 32) < qlen;
+        const int qrow = qoff + (qi < len ? qi : len - 1);
         // Q fragments (B operand of S^T = K Q^T): k-step s, element j <-> d = 16 s + 8 hh + j; split group s of the head
         f16x8 qh[4], ql[4];
         {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
 
         // ---- LDS-DMA of one key tile: K / V pieces into ring slot `buf`, this wave's pair-index tile into its private buffer ------
         const size_t sect = (size_t)(img + 1) * (size_t)a.H * 4 + (size_t)head * 256;
-        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)off * row_bytes + sect;
+        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)qoff * row_bytes + sect;
         const unsigned* idx_base = has_bias ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
         auto issue_kv = [&](int kt, int buf, int jj) __attribute__((always_inline)) {      // piece jj (0..3) of this wave's share
             if (MODE == 2 && (dbg & 4)) return;

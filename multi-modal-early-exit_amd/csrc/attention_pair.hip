@@ -194,10 +194,12 @@ __global__ __launch_bounds__(256, Lds<HP>::WGS) void attention_pair_kernel(const
             hp = pair / n_docs;
             doc = pair - hp * n_docs;
         }
-        const int off = a.doc_off[doc];
+        const int off = a.doc_off[doc];                // context rows and row metadata: current numbering
+        const int qoff = a.qkv_doc_off ? a.qkv_doc_off[doc] : off;      // Q | K | V rows may still be in the previous stage's (probe-first layers)
         const int len = a.doc_off[doc + 1] - off;
+        const int qlen = a.q_limit > 0 && a.q_limit < len ? a.q_limit : len;      // queries wanted (CLS probe: the first block only)
         const int q0 = qt * QT;
-        if (q0 >= len) continue;                       // uniform over the workgroup
+        if (q0 >= qlen) continue;                      // uniform over the workgroup
         unsigned long long tprev = 0;
         if (DIAG) tprev = stamp_now();
 
@@ -219,8 +221,9 @@ __global__ __launch_bounds__(256, Lds<HP>::WGS) void attention_pair_kernel(const
         }
 
         const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
-        const bool wave_active = (q0 + wave * 32) < len;
-        const int qrow = off + (qi < len ? qi : len - 1);
+        const bool wave_active = (q0 + wave * 32) < qlen;
+        const int qrel = qi < len ? qi : len - 1;
+        const int qrow = qoff + qrel;
         // Q fragments (B operand of S^T = K Q^T): k-step s, element j <-> d = 16 s + 8 hh + j; split group s of the head
         f16x8 qh[HP][4], ql[HP][4];
         {
@@ -233,12 +236,12 @@ __global__ __launch_bounds__(256, Lds<HP>::WGS) void attention_pair_kernel(const
                     ql[hd][s] = *reinterpret_cast<const f16x8*>(qp + 256 * hd + 64 * s + 32);
                 }
         }
-        const RowMeta mq = a.meta[qrow];
+        const RowMeta mq = a.meta[off + qrel];
         const int cq1 = ENT * (r1 - mq.pos / 4), cqx = ENT * (r2 - mq.x0 / 4), cqy = ENT * (r2 - mq.y1 / 4);
 
         // ---- LDS-DMA of one key tile (the item's heads' K and V + the keys' metadata) into ring slot `buf` -------------------------
         const size_t sect = (size_t)(img / HP + 1) * (size_t)a.H * 4 + (size_t)(HP * hp + img % HP) * 256;
-        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)off * row_bytes + sect;
+        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)qoff * row_bytes + sect;
         const unsigned long long meta_base = sgpr64((unsigned long long)(size_t)(a.meta + off));
         // piece jj (0 .. PPW-1) of this wave's share of tile kt; jj == PPW: the metadata (wave 3)
         auto issue_piece = [&](int kt, int buf, int jj) __attribute__((always_inline)) {

@@ -66,6 +66,8 @@ struct ee_handle {
     int n1 = 0, c1 = 0, n2 = 0, c2 = 0;
     // workspace
     float *Xs = nullptr, *Ys = nullptr;           // split-f16 copies of X / Y rows (MMEE_PREC_F32_SPLIT)
+    float* patch_s = nullptr;                     // split rows of the patch projection weight (when its shape fits the split kernel)
+    float patch_inv = 1.f;
     float* absmax_dev = nullptr;
     bool split = false;
     unsigned* pair_idx = nullptr;                 // split mode, LayoutLMv3: one word per (query, key) pair of every document (attention_idx.hip)
@@ -73,6 +75,9 @@ struct ee_handle {
     int idx_nb = 0;
     size_t idx_stride = 0;
     float* cls_f32 = nullptr;                     // split mode: CLS rows of the active documents rebuilt from the split planes
+    // CLS probe (probe-first layers): one row per active document
+    float *Yc = nullptr, *Ycs = nullptr, *H1c = nullptr, *Xc = nullptr, *Xcs = nullptr;
+    int* iota = nullptr;                          // 0 .. max_docs-1
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
     int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
     int* queue_heads = nullptr;                   // one work-queue counter per persistent launch of a forward
@@ -96,7 +101,9 @@ struct ee_handle {
     int* err_host = nullptr;
     // bookkeeping of the last forward
     int last_B = 0, last_T = 0, last_stages = 0;
-    std::vector<int> layer_stage;
+    std::vector<int> layer_stage;                 // stage whose rows the layer's attention / attention-out / FFN ran on; -1: none (probe only)
+    std::vector<int> layer_qkv_stage;             // stage whose rows the layer's Q|K|V projection ran on
+    std::vector<int> layer_probe_stage;           // stage whose CLS rows were probed before the layer's exit decision; -1: no probe
     std::vector<int> exit_stage;
     uint32_t last_flags = 0;
     bool last_gate_heads = true;                  // gate strategy: were the 2-way gate heads evaluated in the last forward
@@ -177,7 +184,7 @@ void bucket_lut_host(int num_buckets, int max_distance, int max_delta, unsigned 
 const char* const kProfNames[] = {
     "prep|doc_prep_kernel+doc_scan_kernel+row_meta_kernel",
     "embed_text|embed_text_kernel",
-    "gemm_patch|gemm_f32_kernel<0,1>",
+    "gemm_patch|patch_split_kernel+gemm_split_kernel<.., 0, false> (f32: gemm_f32_kernel<0,1>)",
     "embed_visual|embed_visual_kernel+pool_finish_kernel",
     "gemm_qkv|gemm_f32_kernel<0,0>",
     "attention|attention_f32_kernel",
@@ -189,8 +196,9 @@ const char* const kProfNames[] = {
     "exit_decide|exit_decide_kernel",
     "compact|compact_rows_kernel",
     "gather_cls|gather_cls_kernel",
+    "cls_probe|attention_idx_kernel+gemm_split_kernel<.., 1>+ln_rows_kernel+gather_cls_kernel (CLS rows of an exit layer, before its decision)",
 };
-enum { P_PREP = 0, P_EMBT, P_GPATCH, P_EMBV, P_GQKV, P_ATTN, P_GAO, P_LN, P_GUP, P_GDOWN, P_HEAD, P_DECIDE, P_COMPACT, P_GCLS, P_COUNT };
+enum { P_PREP = 0, P_EMBT, P_GPATCH, P_EMBV, P_GQKV, P_ATTN, P_GAO, P_LN, P_GUP, P_GDOWN, P_HEAD, P_DECIDE, P_COMPACT, P_GCLS, P_PROBE, P_COUNT };
 
 struct ProfScope {
     ee_handle* h;
@@ -432,6 +440,17 @@ int ee_create(const ee_config* c, ee_handle** out) {
             rc |= dev_alloc(h, &h->absmax_dev, 4);
             rc |= dev_alloc(h, &h->cls_f32, Bm * H);
             if (!beit) {
+                rc |= dev_alloc(h, &h->Yc, Bm * H);
+                rc |= dev_alloc(h, &h->Ycs, Bm * H);
+                rc |= dev_alloc(h, &h->H1c, Bm * I);
+                rc |= dev_alloc(h, &h->Xc, Bm * H);
+                rc |= dev_alloc(h, &h->Xcs, Bm * H);
+                rc |= dev_alloc(h, &h->iota, Bm);
+                if (!rc) {
+                    std::vector<int> io(Bm);
+                    for (size_t i = 0; i < Bm; ++i) io[i] = (int)i;
+                    if (hipMemcpy(h->iota, io.data(), sizeof(int) * Bm, hipMemcpyHostToDevice) != hipSuccess) rc = fail(h, "hipMemcpy failed");
+                }
                 h->idx_nb = (int)((Tm + Pv + 31) / 32);
                 h->idx_stride = (size_t)h->idx_nb * h->idx_nb * 1024;
                 rc |= dev_alloc(h, &h->pair_idx, Bm * h->idx_stride);
@@ -451,7 +470,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
         rc |= dev_alloc(h, &h->ntext, Bm);
         rc |= dev_alloc(h, &h->row_src, rows);
         rc |= dev_alloc(h, &h->err_flag, 4);
-        h->n_queue_heads = 128 * (8 * L + 4 * (E + 1) + 16);     // 8 XCD-local heads per launch, one 64-byte line each
+        h->n_queue_heads = 128 * (12 * L + 4 * (E + 1) + 16);     // 8 XCD-local heads per launch, one 64-byte line each
         rc |= dev_alloc(h, &h->queue_heads, (size_t)h->n_queue_heads);
         rc |= dev_alloc(h, &h->meta[0], rows);
         rc |= dev_alloc(h, &h->meta[1], rows);
@@ -582,6 +601,10 @@ int ee_finalize(ee_handle* h) {
             if (build(w.f1_w, I, H, &w.f1_s, &w.f1_inv)) return 1;
             if (build(w.f2_w, H, I, &w.f2_s, &w.f2_inv)) return 1;
         }
+        const int Kp = c.num_channels * c.patch_size * c.patch_size;
+        const size_t NPp = (size_t)(c.input_size / c.patch_size) * (c.input_size / c.patch_size);
+        const bool fits = NPp * Kp <= ((size_t)c.max_text_len + NPp + 1) * I;      // the split patches are staged in H1
+        if (mmee::gemm_split_supports(H, Kp) && c.patch_size % 4 == 0 && fits && build(h->patch_w, H, Kp, &h->patch_s, &h->patch_inv)) return 1;
         HIP_OK(h, hipDeviceSynchronize());
     }
     if (c.arch == MMEE_ARCH_BEIT) {      // absolute position embeddings only: the attention kernel gets one-entry zero tables
@@ -690,15 +713,30 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     bool need[3] = {false, false, false};
     for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
 
+    // patch projection (Conv2d with stride = kernel = a GEMM over flattened patches, HF:75-81) -> vis_raw [B * NP][H].  Split mode:
+    // the patches are written once as split rows (into H1, idle until the first FFN) and the split kernel runs the GEMM; otherwise
+    // the f32 kernel gathers the patches itself.
+    auto patch_projection = [&]() {
+        ProfScope ps(h, P_GPATCH, s);
+        GemmArgs pg{};
+        pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
+        pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
+        pg.tile_counter = next_head(); pg.prio_mode = 1; pg.err_flag = h->err_flag;
+        if (h->split && h->patch_s) {
+            mmee::launch_patch_split(pixel_values, h->H1, B, c.num_channels, c.input_size, c.patch_size, mmee::kSplitScaleX, cus, s, h->err_flag);
+            pg.A = h->H1; pg.lda = pg.K; pg.W = h->patch_s; pg.alpha = h->patch_inv / mmee::kSplitScaleX;
+            launch_gemm_split(pg, EPI_BIAS, B * NP, cus, s);
+            return;
+        }
+        pg.W = h->patch_w;
+        pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
+        launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s);
+    };
+
     if (beit) {
         // ---- BEiT / DiT: uniform 197-row documents, BeitEmbeddings = patch conv + cls + absolute position embeddings ----
         { ProfScope ps(h, P_PREP, s); launch_prep_uniform(B, Pv, S_doc_off(0), S_x_src(0), S_doc_orig(0), h->meta[0], h->counts, s); }
-        GemmArgs pg{};
-        pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
-        pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
-        pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
-        pg.tile_counter = next_head(); pg.prio_mode = 1;
-        { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
+        patch_projection();
         { ProfScope ps(h, P_EMBV, s); launch_embed_beit(h->vis_raw, h->cls_token, c.use_abs_pos ? h->pos_embed : nullptr, B, Pv, H, h->X, s); }
     } else {
     // ---- stage 0: packed layout --------------------------------------------------------------------------------
@@ -732,17 +770,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     ea.ln1_g = h->emb_g; ea.ln1_b = h->emb_b; ea.eps1 = c.layer_norm_eps;
     ea.ln2_g = h->ln_g; ea.ln2_b = h->ln_b; ea.eps2 = c.layer_norm_eps;
     ea.X = h->X;
+    if (h->split) { ea.Xs = h->Xs; ea.split_scale = mmee::kSplitScaleX; ea.err_flag = h->err_flag; }      // split mode: the embeddings exist as split planes only
     ea.text_part = need[MMEE_EXIT_TEXT_AVG] ? h->text_part : nullptr;
     ea.cat_part = need[MMEE_EXIT_TEXT_VISUAL_CONCAT] ? h->cat_part : nullptr;
     ea.cat_chunks = tch + vch;
     { ProfScope ps(h, P_EMBT, s); launch_embed_text(ea, s); }
 
-    GemmArgs pg{};
-    pg.W = h->patch_w; pg.bias = h->patch_b; pg.C = h->vis_raw; pg.ldc = H; pg.m_static = B * NP; pg.N = H;
-    pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
-    pg.pix = pixel_values; pg.C_in = c.num_channels; pg.R = c.input_size; pg.P = c.patch_size; pg.G = G;
-    pg.tile_counter = next_head(); pg.prio_mode = 1;
-    { ProfScope ps(h, P_GPATCH, s); launch_gemm_f32(pg, EPI_BIAS, AMODE_IM2COL, B * NP, cus, s); }
+    patch_projection();
 
     EmbedArgs va = ea;
     va.ln1_g = h->norm_g; va.ln1_b = h->norm_b; va.eps1 = 1e-6f;        // layoutlmv3.norm = LayerNorm(eps=1e-6), HF:563
@@ -759,8 +793,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     }
 
     const bool sp = h->split;
-    if (sp && !beit)     // the first QKV projection reads split-f16 rows; later layers get them from the LayerNorm kernel
-        mmee::launch_split_rows(h->X, h->Xs, &h->counts[0].n_rows, 0, max_rows, H, mmee::kSplitScaleX, cus, s, h->err_flag);
+    // split mode, LayoutLMv3: the embedding kernels wrote the rows as split planes (Xs); later layers get theirs from the LayerNorm kernel
     auto run_gemm = [&](const GemmArgs& g, int epi) {
         if (sp) launch_gemm_split(g, epi, max_rows, cus, s);
         else launch_gemm_f32(g, epi, AMODE_ROWS, max_rows, cus, s);
@@ -776,8 +809,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     };
     const int* x_phys = S_x_src(0);
     bool use_row_src = false;
-    h->layer_stage.assign(L, 0);
+    h->layer_stage.assign(L, -1);
+    h->layer_qkv_stage.assign(L, -1);
+    h->layer_probe_stage.assign(L, -1);
     h->exit_stage.assign(E + 1, 0);
+    static const bool probe_on = [] { const char* e = getenv("MMEE_PROBE"); return !(e && e[0] == '0'); }();   // MMEE_PROBE=0: whole layers (A/B)
+    bool cls_ready = false;
 
     auto run_head = [&](const HeadW& hw, const float* in, int ld, const int* gather, float* hid, float* out) {
         const int* n_docs_ptr = &h->counts[cur].n_docs;
@@ -847,15 +884,16 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         run_exit(&h->emb_heads[kind], h->pooled[kind], H, S_doc_orig(cur), false);
     }
     if (out_hidden_cls)
-        launch_gather_cls(h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls, B, s);
+        launch_gather_cls((sp && !beit) ? h->Xs : h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls, B, s,
+                          (sp && !beit) ? 1.0f / mmee::kSplitScaleX : 0.f);
 
     int next_enc = 0;
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         const int* rows_ptr = &h->counts[cur].n_rows;
         const int* rs = use_row_src ? h->row_src : nullptr;
-        h->layer_stage[l] = cur;
         if (beit) {
+            h->layer_stage[l] = h->layer_qkv_stage[l] = cur;
             // BeitLayer.forward (BEIT:406-444): pre-LN, layer scale.  Z = CTX buffer (LN output / attention output by turns)
             GemmArgs g{};
             { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
@@ -887,40 +925,111 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
         } else {
-        GemmArgs g{};
-        // QKV projection, Q pre-divided by sqrt(d) (HF:263)
-        g.A = sp ? h->Xs : h->X; g.lda = H; g.row_src = rs; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
-        g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
-        g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
-        { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
-        AttnArgs at{};
-        at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
-        at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
-        at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
-        at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
-        fill_idx(at);
-        { ProfScope ps(h, P_ATTN, s); if (sp && use_idx && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s); else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else launch_attention_f32(at, B, cus, s); }
-        // attention output dense + residual (HF:299-303), then LayerNorm
-        g = GemmArgs{};
-        g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = rs;
-        g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
-        g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
-        g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
-        { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
-        // split mode: the LayerNorm output exists only as split planes (22 bits); its readers (next GEMM, residual adds, exit heads) take it from there
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->Y, nullptr, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX, h->err_flag); }
-        // FFN (HF:485-512)
-        g = GemmArgs{};
-        g.A = sp ? h->Ys : h->Y; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
-        g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
-        { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
-        g = GemmArgs{};
-        g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = sp ? h->Ys : h->Y; g.ldr = H;
-        g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
-        g.alpha = w.f2_inv / mmee::kSplitScaleH1;
-        g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
-        { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
-        { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->X, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }
+        // ---- LayoutLMv3 layer (HF:485-512), in three pieces so that an exit layer can decide BEFORE its bulk runs ----------------
+        // Q | K | V projection of every row of the stage, Q pre-divided by sqrt(d) (HF:263)
+        auto layer_qkv = [&]() {
+            GemmArgs g{};
+            g.A = sp ? h->Xs : h->X; g.lda = H; g.row_src = rs; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
+            g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
+            g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
+            h->layer_qkv_stage[l] = cur;
+        };
+        auto attn_args = [&]() {
+            AttnArgs at{};
+            at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
+            at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
+            at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
+            at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
+            fill_idx(at);
+            return at;
+        };
+        auto run_attn = [&](const AttnArgs& at) {
+            if (sp && use_idx && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s);
+            else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s);
+            else launch_attention_f32(at, B, cus, s);
+        };
+        // attention, attention output dense + residual + LayerNorm (HF:299-303), FFN + residual + LayerNorm, on the rows of stage `cur`;
+        // x_rows: physical Xs row of every row of the stage (null: dense), qkv_off: where the documents' Q | K | V rows are (null: dense)
+        auto layer_rest = [&](const int* x_rows, const int* qkv_off) {
+            const int* rp = &h->counts[cur].n_rows;
+            AttnArgs at = attn_args();
+            at.qkv_doc_off = qkv_off;
+            { ProfScope ps(h, P_ATTN, s); run_attn(at); }
+            GemmArgs g{};
+            g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = x_rows;
+            g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
+            g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
+            g.m_ptr = rp; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
+            // split mode: the LayerNorm output exists only as split planes (22 bits); its readers (next GEMM, residual adds, exit heads) take it from there
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->Y, nullptr, rp, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->Ys : nullptr, mmee::kSplitScaleX, h->err_flag); }
+            g = GemmArgs{};
+            g.A = sp ? h->Ys : h->Y; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rp; g.N = I; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
+            { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
+            g = GemmArgs{};
+            g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = sp ? h->Ys : h->Y; g.ldr = H;
+            g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
+            g.alpha = w.f2_inv / mmee::kSplitScaleH1;
+            g.m_ptr = rp; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->X, nullptr, rp, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }
+            h->layer_stage[l] = cur;
+        };
+        // CLS probe: the layer's output for the CLS row of every active document, nothing else.  The exit head (and the final classifier)
+        // only ever read that row, and a row's arithmetic does not depend on which other rows share its launch, so the value is the one
+        // the whole layer would have produced, bit for bit (tests/test_gpu_api.py: early exit == the dump-all row; the dump runs whole layers).
+        auto layer_probe = [&]() {
+            ProfScope ps(h, P_PROBE, s);
+            const int* nd = &h->counts[cur].n_docs;
+            AttnArgs at = attn_args();
+            at.q_limit = 32; at.max_len = max_len < 32 ? max_len : 32;     // the first 32-query block of every document; row 0 is used
+            run_attn(at);
+            // the probe GEMMs are a few dozen tiles: static tile assignment (no queue: the pops would cost more than the tiles)
+            GemmArgs g{};                    // CLS rows only: A = context row doc_off[i], residual = the document's CLS row of Xs
+            g.A = h->CTX; g.lda = H; g.row_src = S_doc_off(cur); g.W = w.ao_s; g.bias = w.ao_b; g.C = h->Yc; g.ldc = H;
+            g.resid = h->Xs; g.ldr = H; g.resid_row_src = x_phys; g.resid_split_inv = 1.0f / mmee::kSplitScaleX;
+            g.alpha = w.ao_inv / mmee::kSplitScaleCtx; g.probe = 1;
+            g.m_ptr = nd; g.N = H; g.K = H; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+            launch_gemm_split(g, EPI_RESID, B, cus, s);
+            launch_ln_rows(h->Yc, nullptr, nullptr, nd, B, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, h->Ycs, mmee::kSplitScaleX, h->err_flag);
+            g = GemmArgs{};
+            g.A = h->Ycs; g.lda = H; g.W = w.f1_s; g.bias = w.f1_b; g.C = h->H1c; g.ldc = I; g.m_ptr = nd; g.N = I; g.K = H; g.scale = 1.f;
+            g.prio_mode = 1; g.err_flag = h->err_flag; g.probe = 1;
+            g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = 1; g.out_scale = mmee::kSplitScaleH1;
+            launch_gemm_split(g, EPI_GELU, B, cus, s);
+            g = GemmArgs{};
+            g.A = h->H1c; g.lda = I; g.W = w.f2_s; g.bias = w.f2_b; g.C = h->Xc; g.ldc = H; g.resid = h->Ycs; g.ldr = H;
+            g.resid_split_inv = 1.0f / mmee::kSplitScaleX; g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.probe = 1;
+            g.m_ptr = nd; g.N = H; g.K = I; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+            launch_gemm_split(g, EPI_RESID, B, cus, s);
+            launch_ln_rows(h->Xc, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Xcs, mmee::kSplitScaleX, h->err_flag);
+            launch_gather_cls(h->Xcs, H, h->iota, nullptr, nd, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
+            h->layer_probe_stage[l] = cur;
+        };
+
+        const bool exit_here = next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1;
+        const bool last = l == L - 1;
+        // probe first: this layer ends in a decision (an exit head, or the final classifier), split attention kernels, no dump of
+        // every layer (the dump keeps every document to the end, so nothing would be saved)
+        const bool probe = probe_on && sp && !no_exit && (exit_here != last);
+        layer_qkv();
+        if (probe) {
+            layer_probe();
+            if (out_hidden_cls)
+                launch_gather_cls(h->Xcs, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s,
+                                  1.0f / mmee::kSplitScaleX);
+            if (last) { cls_ready = true; break; }       // the final classifier below reads cls_f32
+            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);       // compacts: `cur` is now the stage of the documents that stay
+            ++next_enc;
+            // the rest of the layer, for those documents only; their Q | K | V rows are where the previous stage's numbering put them
+            layer_rest(h->row_src, S_meta_src(cur));
+            x_phys = S_doc_off(cur);
+            use_row_src = false;
+            continue;
+        }
+        layer_rest(rs, nullptr);
         }
         // the layer wrote X densely in the numbering of stage `cur`
         x_phys = S_doc_off(cur);
@@ -946,7 +1055,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         launch_ln_rows(h->pooled[0], h->pooled[0], nullptr, &h->counts[cur].n_docs, B, H, h->ln_g, h->ln_b, c.layer_norm_eps, cus, s);
         run_exit(nullptr, h->pooled[0], H, nullptr, true);
     } else if (sp && L > 0) {
-        launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
+        if (!cls_ready) launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
         run_exit(nullptr, h->cls_f32, H, nullptr, true);
     } else {
         run_exit(nullptr, h->X, H, x_phys, true);
@@ -977,7 +1086,7 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
         return fail(h, "ee_forward: internal error (flags %d): the attention kernel found its dynamic LDS region away from address 0", err);
     if (err & mmee::kErrSplitOverflow)
         return fail(h, "ee_forward: split-precision overflow (flags %d): an activation left the range of the split-f16 planes (|LayerNorm out|, "
-                       "|Q/sqrt(d)|, |K|, |V|, |GELU out| <= 3750, |attention context| <= 937) and was clamped, so the result is WRONG; "
+                       "|Q/sqrt(d)|, |K|, |V|, |GELU out|, |pixel_values| <= 3750, |attention context| <= 937) and was clamped, so the result is WRONG; "
                        "run this checkpoint with precision \"fp32\"", err);
     if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id, 8 = token_type id)", err);
     return 0;
@@ -992,10 +1101,13 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
     const double H = c.hidden_size, I = c.intermediate_size;
     const int G = c.input_size / c.patch_size;
     double gf = 2.0 * h->last_B * G * G * (double)(c.num_channels * c.patch_size * c.patch_size) * H, af = 0.0;
-    for (int l = 0; l < c.num_hidden_layers; ++l) {
-        const StageCounts& s = sc[h->layer_stage[l]];
-        gf += 2.0 * s.n_rows * (4.0 * H * H + 2.0 * H * I);
-        af += 4.0 * (double)s.sum_len_sq * H;
+    for (int l = 0; l < c.num_hidden_layers; ++l) {      // the CLS probes are not in here: ee_last_layer_plan reports them
+        if (h->layer_qkv_stage[l] >= 0) gf += 2.0 * sc[h->layer_qkv_stage[l]].n_rows * 3.0 * H * H;
+        if (h->layer_stage[l] >= 0) {
+            const StageCounts& s = sc[h->layer_stage[l]];
+            gf += 2.0 * s.n_rows * (H * H + 2.0 * H * I);
+            af += 4.0 * (double)s.sum_len_sq * H;
+        }
     }
     const int E = h->last_stages - 1;
     const double ko = c.strategy == MMEE_STRATEGY_RAMP ? c.num_labels : 2;
@@ -1009,6 +1121,28 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
     }
     if (gemm_flops) *gemm_flops = gf;
     if (attn_flops) *attn_flops = af;
+    return 0;
+}
+
+int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int32_t* docs_probe, int32_t cap, double* probe_flops, void* stream) {
+    if (!h || !h->last_stages) return fail(h, "ee_last_layer_plan: no forward has run");
+    HIP_OK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<StageCounts> sc(h->last_stages);
+    HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * h->last_stages, hipMemcpyDeviceToHost));
+    const ee_config& c = h->cfg;
+    const double H = c.hidden_size, I = c.intermediate_size;
+    double pf = 0.0;
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+        const int q = h->layer_qkv_stage[l], m = h->layer_stage[l], p = h->layer_probe_stage[l];
+        if (l < cap) {
+            if (rows_qkv) rows_qkv[l] = q >= 0 ? sc[q].n_rows : 0;
+            if (rows_main) rows_main[l] = m >= 0 ? sc[m].n_rows : 0;
+            if (docs_probe) docs_probe[l] = p >= 0 ? sc[p].n_docs : 0;
+        }
+        // probe: 32 queries x every key of the document (QK^T and PV), then attention-out + FFN on one row per document
+        if (p >= 0) pf += 4.0 * 32.0 * sc[p].n_rows * H + 2.0 * sc[p].n_docs * (H * H + 2.0 * H * I);
+    }
+    if (probe_flops) *probe_flops = pf;
     return 0;
 }
 

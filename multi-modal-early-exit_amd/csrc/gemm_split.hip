@@ -66,6 +66,11 @@ using CfgB = SplitCfg<256, 256, 128, 2, 4, 4, 1>;
 // random operands holds 1.62 GHz = 1674 TFLOP/s, a bare 16x16x32 loop 1.89 GHz = 1945 TFLOP/s): the 16x16x32 form moves
 // half the accumulator bits per MAC, and the clock the chip can hold rises with it.
 using CfgC = SplitCfg<256, 256, 128, 2, 4, 4, 1, 16>;
+// CfgP: the CLS-probe GEMMs (M = documents of the stage, a few hundred rows).  Those launches are a handful of tiles whose k-loop
+// is bound by the latency of one DMA stage, not by the matrix pipe: 64x128 tiles on 2 waves give 8x the tiles of CfgC, and the
+// 3-deep ring keeps two stages in flight.  Per output element the MFMA sequence is CfgC's (same 16x16x32 form, same k order, same
+// term order), so the results are CfgC's bit for bit.
+using CfgP = SplitCfg<64, 128, 128, 3, 1, 2, 2, 16>;
 
 bool gemm_split_supports(int N, int K) { return N > 0 && K > 0 && N % 256 == 0 && K % 32 == 0; }
 
@@ -226,7 +231,9 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
     if (OUT_SPLIT) split_flag_overflow(amax, g.err_flag);
 }
 
-template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false>
+// TAG only names the instantiation (1 = the CLS-probe launches of capi.hip, so that a profiler keeps them apart from the
+// layer's own GEMMs); the code is the same, and so is every result bit.
+template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0>
 __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmArgs g) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, ROWB = Cfg::ROWB, NST = Cfg::NST, WN = Cfg::WN, PA = Cfg::PA, PW = Cfg::PW;
     constexpr int STAGE_BYTES = Cfg::STAGE_BYTES, A_BYTES = Cfg::A_BYTES;
@@ -385,8 +392,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             } else if (dbg & 4) {                    // diagnostic: no DMA wait
                 asm volatile("s_barrier" ::: "memory");
             } else if (NST == 3 && kt + 1 < nk) {
+                static_assert(Cfg::PP == 3 || Cfg::PP == 4 || Cfg::PP == 12, "vmcnt immediate: one stage's pieces per wave");
                 if (Cfg::PP == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                else if (Cfg::PP == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
@@ -483,12 +492,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     }
 }
 
-template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false>
+template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0>
 static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = Cfg::LOOP_BYTES + 16;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
@@ -496,13 +505,19 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
     int grid = Cfg::WGS * num_cus;
     if (grid > tiles) grid = tiles;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
+    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
 }
 
 // CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283);
 // MMEE_SPLIT_CFG=A / B force the other configurations (A/B measurements).
 void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
     static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : e[0] == 'C' ? 3 : 0) : 0; }();
+    if (a.probe && !a.dbg_noload && (forced == 3 || forced == 0)) {      // CLS probe: the default configuration under its own kernel name
+        if (a.out_split && epi == EPI_GELU) launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s);
+        else if (!a.out_split && epi == EPI_RESID) launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s);
+        else abort();                    // the probe launches no other shape
+        return;
+    }
     if ((forced == 3 || forced == 0) && !a.dbg_noload) {      // default: CfgC
         if (a.out_split) {
             if (epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true>(a, max_m, num_cus, s);
@@ -573,6 +588,35 @@ void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n
     int grid = (int)(blocks < (size_t)num_cus * 16 ? blocks : (size_t)num_cus * 16);
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(split_rows_kernel, dim3(grid), dim3(256), 0, s, src, reinterpret_cast<char*>(dst), n_rows_ptr, n_rows_static, K, scale, err_flag);
+}
+
+// pixel_values [B][C][R][R] -> split rows [B * G * G][C * P * P] (one row per patch, k = (c, py, px) as Conv2d's weight flattens,
+// HF:75-81): the A operand of the patch projection on the split kernel.  P % 4 == 0: four consecutive k are four consecutive pixels.
+__global__ __launch_bounds__(256) void patch_split_kernel(const float* __restrict__ pix, char* __restrict__ dst, int n_patches, int C, int R,
+                                                          int P, int G, float scale, int* __restrict__ err_flag) {
+    const int K = C * P * P, k4 = K / 4;
+    const size_t total = (size_t)n_patches * k4;
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / k4;
+        const int k = (int)(i - r * k4) * 4;
+        const int b = (int)(r / (size_t)(G * G)), pr = (int)(r - (size_t)b * (G * G));
+        const int gy = pr / G, gx = pr - gy * G;
+        const int c = k / (P * P), rem = k - c * P * P;
+        const int py = rem / P, px = rem - py * P;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pix + (((size_t)b * C + c) * R + (size_t)(gy * P + py)) * R + gx * P + px);
+        store_split4(dst + r * (size_t)K * 4, k, v, scale, amax);
+    }
+    split_flag_overflow(amax, err_flag);
+}
+
+void launch_patch_split(const float* pix, void* dst, int n_docs, int C, int R, int P, float scale, int num_cus, hipStream_t s, int* err_flag) {
+    const int G = R / P;
+    const size_t total = (size_t)n_docs * G * G * (C * P * P / 4);
+    size_t blocks = (total + 255) / 256;
+    int grid = (int)(blocks < (size_t)num_cus * 16 ? blocks : (size_t)num_cus * 16);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(patch_split_kernel, dim3(grid), dim3(256), 0, s, pix, reinterpret_cast<char*>(dst), n_docs * G * G, C, R, P, G, scale, err_flag);
 }
 
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ src, size_t n, float* __restrict__ out) {

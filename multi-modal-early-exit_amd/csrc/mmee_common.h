@@ -222,6 +222,7 @@ struct GemmArgs {
     int out_split;                   // 1: C is written as split rows (planes of ldc columns) scaled by out_scale
     float out_scale;
     int use_dma;                     // 0 = default (LDS-DMA kernel unless MMEE_GEMM_DMA=0), 1 = LDS-DMA kernel, 2 = register-staged kernel
+    int probe;                       // split kernel: 1 = the CLS-probe instantiation (same code, its own kernel name for the profiler)
     int prio_mode;                   // 0 none, 1 raise the priority of odd hardware wave slots, 2 of the second half of the grid
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
     int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
@@ -255,6 +256,10 @@ struct AttnArgs {
     const float *w1, *wx, *wy;       // rel_pos_bias / rel_pos_x_bias / rel_pos_y_bias weights, [heads][bins]
     int bins1, bins2;
     float inv_sqrt_d;
+    // probe-first layers (capi.hip): the split attention kernels only
+    const int* qkv_doc_off;          // [n_docs] row offsets of the documents' Q | K | V rows when those are still in the previous stage's
+                                     // numbering; null: doc_off
+    int q_limit;                     // > 0: only queries < q_limit of every document (the CLS probe asks for the first block)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -266,6 +271,8 @@ bool gemm_split_supports(int N, int K);
 // f32 rows -> split rows (n_rows_ptr null -> n_rows_static); src row r is src[row_src ? row_src[r] : r]
 void launch_split_rows(const float* src, void* dst, const int* n_rows_ptr, int n_rows_static, int max_rows, int K, float scale,
                        int num_cus, hipStream_t s, int* err_flag = nullptr);
+// pixel_values -> split rows of flattened patches (the patch projection's A operand); needs patch_size % 4 == 0
+void launch_patch_split(const float* pix, void* dst, int n_docs, int C, int R, int P, float scale, int num_cus, hipStream_t s, int* err_flag);
 void launch_absmax(const float* src, size_t n, float* out_dev, hipStream_t s);   // *out_dev = max |src[i]| (out zeroed by the launcher)
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 unsigned long long* attention_pair_stamps();

@@ -41,6 +41,9 @@ struct EmbedArgs {
     float eps2;
     const float *cls_token, *pos_embed, *vis_raw;
     float* X;
+    void* Xs;                        // when given, the rows are written as split-f16 planes (x split_scale) here and X is not written
+    float split_scale;
+    int* err_flag;                   // Xs: kErrSplitOverflow
     float* text_part;                // (B, ceil(T/32), H) or null
     float* vis_part;                 // (B, ceil(Pv/32), H) or null
     float* cat_part;                 // (B, cat_chunks, H) or null; text chunks first, then visual chunks

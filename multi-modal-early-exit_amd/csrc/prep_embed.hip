@@ -169,6 +169,16 @@ __device__ __forceinline__ void wave_store_row(float* __restrict__ dst, const f3
     }
 }
 
+// the same row as split-f16 planes (the A operand of the first Q|K|V projection, the residual of the first attention output)
+template <int NV>
+__device__ __forceinline__ void wave_store_row_split(void* dst_row, const f32x4 (&x)[NV], int H, int lane, float scale, float& amax) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < H) store_split4(dst_row, c, x[i], scale, amax);
+    }
+}
+
 // reduce per-wave column sums of the 4 waves through LDS and write one partial row
 template <int NV>
 __device__ __forceinline__ void block_write_partial(float* lds, float* __restrict__ dst, const f32x4 (&acc)[NV],
@@ -196,10 +206,14 @@ __global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { acc_t[i] = f32x4{0, 0, 0, 0}; acc_c[i] = f32x4{0, 0, 0, 0}; }
     const int doff = a.doc_off[b];
+    const bool pooled = a.text_part || a.cat_part;            // the pooled embedding exits average over every position, padding included
+    float amax = 0.f;
     for (int t = 0; t < 8; ++t) {
         const int j = ch * 32 + wave * 8 + t;
         if (j >= T) break;                                    // wave-uniform
         const size_t tok = (size_t)b * T + j;
+        const int dst = a.text_dst[tok];
+        if (dst < 0 && !pooled) continue;                     // a padded position: no packed row, and nobody averages over it (wave-uniform)
         // out-of-range ids are reported through err_flag by doc_prep_kernel; here they are clamped so that the table
         // lookups stay inside the tables (as bbox and position ids are)
         long long id = a.input_ids[tok];
@@ -262,9 +276,12 @@ __global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
         wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);      // layoutlmv3.LayerNorm (after the concat)
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
-        const int dst = a.text_dst[tok];
-        if (dst >= 0) wave_store_row<NV>(a.X + (size_t)(doff + dst) * H, x, H, lane);
+        if (dst >= 0) {
+            if (a.Xs) wave_store_row_split<NV>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + dst) * H * 4, x, H, lane, a.split_scale, amax);
+            else wave_store_row<NV>(a.X + (size_t)(doff + dst) * H, x, H, lane);
+        }
     }
+    if (a.Xs) split_flag_overflow(amax, a.err_flag);
     if (a.text_part) block_write_partial<NV>(lds, a.text_part + ((size_t)b * nch + ch) * H, acc_t, H, lane, wave);
     if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + ch) * H, acc_c, H, lane, wave);
 }
@@ -281,6 +298,7 @@ __global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) { acc_v[i] = f32x4{0, 0, 0, 0}; acc_c[i] = f32x4{0, 0, 0, 0}; }
     const int doff = a.doc_off[b] + a.ntext[b];
+    float amax = 0.f;
     for (int t = 0; t < 8; ++t) {
         const int v = ch * 32 + wave * 8 + t;
         if (v >= Pv) break;
@@ -302,8 +320,10 @@ __global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
         wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
-        wave_store_row<NV>(a.X + (size_t)(doff + v) * H, x, H, lane);
+        if (a.Xs) wave_store_row_split<NV>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + v) * H * 4, x, H, lane, a.split_scale, amax);
+        else wave_store_row<NV>(a.X + (size_t)(doff + v) * H, x, H, lane);
     }
+    if (a.Xs) split_flag_overflow(amax, a.err_flag);
     if (a.vis_part) block_write_partial<NV>(lds, a.vis_part + ((size_t)b * nch + ch) * H, acc_v, H, lane, wave);
     if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + tch + ch) * H, acc_c, H, lane, wave);
 }

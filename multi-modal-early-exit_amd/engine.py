@@ -281,7 +281,20 @@ class EarlyExitEngine:
         with torch.cuda.device(self.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             capi.check(self.lib.ee_last_flops(self._h, C.byref(g), C.byref(a), stream), self._h, "ee_last_flops")
-        return {"gemm": g.value, "attention": a.value, "total": g.value + a.value}
+        plan = self.layer_plan()
+        return {"gemm": g.value, "attention": a.value, "probe": plan["probe_flops"],
+                "total": g.value + a.value + plan["probe_flops"]}
+
+    def layer_plan(self):
+        """How the last forward ran each encoder layer (ee_last_layer_plan): rows through Q|K|V, rows through the rest of
+        the layer, documents whose CLS row was probed before the layer's decision."""
+        L = self.cfg.num_hidden_layers
+        q, m, p = (C.c_int32 * L)(), (C.c_int32 * L)(), (C.c_int32 * L)()
+        pf = C.c_double()
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(self.lib.ee_last_layer_plan(self._h, q, m, p, L, C.byref(pf), stream), self._h, "ee_last_layer_plan")
+        return {"rows_qkv": list(q), "rows_main": list(m), "docs_probe": list(p), "probe_flops": pf.value}
 
 
 def load_checkpoint_tensors(path: str) -> Dict[str, "torch.Tensor"]:
