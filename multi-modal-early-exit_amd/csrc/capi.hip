@@ -824,7 +824,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (hw.dense_w) {
             GemmArgs g{};
             g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
-            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            // a handful of tiles: static assignment (walking the eight XCD queues would cost more than the tiles)
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
             launch_gemm_f32(g, EPI_TANH, AMODE_ROWS, B, cus, s);
             hin = hid; hld = H; hg = nullptr;
         }

@@ -67,10 +67,11 @@ using CfgB = SplitCfg<256, 256, 128, 2, 4, 4, 1>;
 // half the accumulator bits per MAC, and the clock the chip can hold rises with it.
 using CfgC = SplitCfg<256, 256, 128, 2, 4, 4, 1, 16>;
 // CfgP: the CLS-probe GEMMs (M = documents of the stage, a few hundred rows).  Those launches are a handful of tiles whose k-loop
-// is bound by the latency of one DMA stage, not by the matrix pipe: 64x128 tiles on 2 waves give 8x the tiles of CfgC, and the
-// 3-deep ring keeps two stages in flight.  Per output element the MFMA sequence is CfgC's (same 16x16x32 form, same k order, same
-// term order), so the results are CfgC's bit for bit.
-using CfgP = SplitCfg<64, 128, 128, 3, 1, 2, 2, 16>;
+// is bound by the latency of a stage, not by the matrix pipe.  Measured on the six probes of one bench step (three GEMMs each):
+// CfgC 1.80 ms, 64x128 on 2 waves 1.73 ms, 128x256 on 8 waves 1.26 ms, 128x128 on 4 waves with the 3-deep ring 0.91 ms (one wave
+// per SIMD, two stages in flight).  Per output element the MFMA sequence is CfgC's (same 16x16x32 form, same k order, same term
+// order), so the results are CfgC's bit for bit.
+using CfgP = SplitCfg<128, 128, 128, 3, 2, 2, 1, 16>;
 
 bool gemm_split_supports(int N, int K) { return N > 0 && K > 0 && N % 256 == 0 && K % 32 == 0; }
 
@@ -392,10 +393,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             } else if (dbg & 4) {                    // diagnostic: no DMA wait
                 asm volatile("s_barrier" ::: "memory");
             } else if (NST == 3 && kt + 1 < nk) {
-                static_assert(Cfg::PP == 3 || Cfg::PP == 4 || Cfg::PP == 12, "vmcnt immediate: one stage's pieces per wave");
+                static_assert(Cfg::PP == 3 || Cfg::PP == 4 || Cfg::PP == 8, "vmcnt immediate: one stage's pieces per wave");
                 if (Cfg::PP == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
                 else if (Cfg::PP == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }

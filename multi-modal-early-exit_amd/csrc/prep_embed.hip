@@ -193,43 +193,65 @@ __device__ __forceinline__ void block_write_partial(float* lds, float* __restric
     for (int c = threadIdx.x; c < H; c += 256) dst[c] = (lds[c] + lds[H + c]) + (lds[2 * H + c] + lds[3 * H + c]);
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
+template <int NV, bool FAST, bool POOLED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void embed_text_kernel(EmbedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int T = a.T, H = a.H;
     const int nch = (T + 31) / 32;
     const int b = blockIdx.x / nch, ch = blockIdx.x - b * nch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cs = a.cs, ss = a.ss, hi = a.max_2d - 1;
-    const bool fast = ((cs & 3) == 0) && ((ss & 3) == 0);
     f32x4 acc_t[NV], acc_c[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { acc_t[i] = f32x4{0, 0, 0, 0}; acc_c[i] = f32x4{0, 0, 0, 0}; }
     const int doff = a.doc_off[b];
-    const bool pooled = a.text_part || a.cat_part;            // the pooled embedding exits average over every position, padding included
+    constexpr bool pooled = POOLED;                           // the pooled embedding exits (text_part / cat_part) average over every position, padding included
     float amax = 0.f;
-    for (int t = 0; t < 8; ++t) {
-        const int j = ch * 32 + wave * 8 + t;
-        if (j >= T) break;                                    // wave-uniform
-        const size_t tok = (size_t)b * T + j;
-        const int dst = a.text_dst[tok];
-        if (dst < 0 && !pooled) continue;                     // a padded position: no packed row, and nobody averages over it (wave-uniform)
+    // The kernel is bound by memory latency, not traffic: per position, ids -> table rows -> two LayerNorms -> store, and a wave walks
+    // its 8 positions in turn.  So (1) lane t fetches the ids / box / position of the wave's position t, all 8 at once, and the loop
+    // reads them back with v_readlane; (2) the table rows of position t + 1 are in flight while position t is normalised; (3) the
+    // registers stay few (no unrolling over positions, branch-free addressing of the spatial tables): many waves per SIMD.
+    const int j0 = ch * 32 + wave * 8;
+    int m_id = 0, m_tt = 0, m_pid = 0, m_dst = -1, m_b0 = 0, m_b1 = 0, m_b2 = 0, m_b3 = 0;
+    if (lane < 8 && j0 + lane < T) {
+        const size_t tok = (size_t)b * T + j0 + lane;
         // out-of-range ids are reported through err_flag by doc_prep_kernel; here they are clamped so that the table
         // lookups stay inside the tables (as bbox and position ids are)
-        long long id = a.input_ids[tok];
-        id = id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id);
-        long long ttl = a.token_type_ids ? a.token_type_ids[tok] : 0;
-        const int tt = (int)(ttl < 0 ? 0 : (ttl >= a.type_vocab ? a.type_vocab - 1 : ttl));
-        const int pid = a.emb_pos[tok];
-        int bb[4];
+        const long long id = a.input_ids[tok];
+        m_id = (int)(id < 0 ? 0 : (id >= a.vocab ? a.vocab - 1 : id));
+        const long long ttl = a.token_type_ids ? a.token_type_ids[tok] : 0;
+        m_tt = (int)(ttl < 0 ? 0 : (ttl >= a.type_vocab ? a.type_vocab - 1 : ttl));
+        m_pid = a.emb_pos[tok];
+        m_dst = a.text_dst[tok];
+        const long long v0 = a.bbox[tok * 4], v1 = a.bbox[tok * 4 + 1], v2 = a.bbox[tok * 4 + 2], v3 = a.bbox[tok * 4 + 3];
+        m_b0 = (int)(v0 < 0 ? 0 : (v0 > hi ? hi : v0));
+        m_b1 = (int)(v1 < 0 ? 0 : (v1 > hi ? hi : v1));
+        m_b2 = (int)(v2 < 0 ? 0 : (v2 > hi ? hi : v2));
+        m_b3 = (int)(v3 < 0 ? 0 : (v3 > hi ? hi : v3));
+    }
+    // spatial embedding = cat(x0, y0, x1, y1 rows of the x / y tables (cs wide each), h row, w row (ss wide each)), HF:118-134.
+    // FAST (cs, ss multiples of 4): this lane's 4 columns of chunk i sit inside ONE of the six segments, fixed for the whole kernel
+    const float* seg_tab[NV];
+    int seg_sel[NV], seg_stride[NV];
+    if constexpr (FAST) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            long long v = a.bbox[tok * 4 + c];
-            bb[c] = (int)(v < 0 ? 0 : (v > hi ? hi : v));
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            int sel, col;
+            if (c < 4 * cs) { sel = c / cs; col = c - sel * cs; }
+            else if (c < 4 * cs + ss) { sel = 4; col = c - 4 * cs; }
+            else { sel = 5; col = c - 4 * cs - ss; }
+            seg_sel[i] = sel;
+            seg_stride[i] = sel < 4 ? cs : ss;
+            seg_tab[i] = (sel == 4 ? a.htab : sel == 5 ? a.wtab : (sel & 1) ? a.ytab : a.xtab) + col;
         }
-        int hidx = bb[3] - bb[1]; hidx = hidx < 0 ? 0 : (hidx > hi ? hi : hidx);   // clip(y1 - y0, 0, 1023) HF:121
-        int widx = bb[2] - bb[0]; widx = widx < 0 ? 0 : (widx > hi ? hi : widx);   // clip(x1 - x0, 0, 1023) HF:122
-        f32x4 x[NV];
+    }
+    auto load_row = [&](int t, f32x4 (&x)[NV]) __attribute__((always_inline)) {
+        const int id = __builtin_amdgcn_readlane(m_id, t), tt = __builtin_amdgcn_readlane(m_tt, t), pid = __builtin_amdgcn_readlane(m_pid, t);
+        const int b0 = __builtin_amdgcn_readlane(m_b0, t), b1 = __builtin_amdgcn_readlane(m_b1, t);
+        const int b2 = __builtin_amdgcn_readlane(m_b2, t), b3 = __builtin_amdgcn_readlane(m_b3, t);
+        int hidx = b3 - b1; hidx = hidx < 0 ? 0 : (hidx > hi ? hi : hidx);   // clip(y1 - y0, 0, 1023) HF:121
+        int widx = b2 - b0; widx = widx < 0 ? 0 : (widx > hi ? hi : widx);   // clip(x1 - x0, 0, 1023) HF:122
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
@@ -238,18 +260,12 @@ __global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
                 v += *reinterpret_cast<const f32x4*>(a.type + (size_t)tt * H + c);
                 v += *reinterpret_cast<const f32x4*>(a.pos + (size_t)pid * H + c);
                 f32x4 sp;
-                if (fast) {
-                    const float* p;
-                    if (c < 4 * cs) {
-                        const int seg = c / cs, col = c - seg * cs;
-                        p = ((seg & 1) ? a.ytab : a.xtab) + (size_t)bb[seg] * cs + col;
-                    } else if (c < 4 * cs + ss) {
-                        p = a.htab + (size_t)hidx * ss + (c - 4 * cs);
-                    } else {
-                        p = a.wtab + (size_t)widx * ss + (c - 4 * cs - ss);
-                    }
-                    sp = *reinterpret_cast<const f32x4*>(p);
+                if constexpr (FAST) {
+                    const int sel = seg_sel[i];
+                    const int idx = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : sel == 3 ? b3 : sel == 4 ? hidx : widx;
+                    sp = *reinterpret_cast<const f32x4*>(seg_tab[i] + (size_t)idx * seg_stride[i]);
                 } else {
+                    const int bb[4] = {b0, b1, b2, b3};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int cc = c + e;
@@ -270,20 +286,43 @@ __global__ __launch_bounds__(256) void embed_text_kernel(EmbedArgs a) {
                 x[i] = f32x4{0, 0, 0, 0};
             }
         }
+    };
+    // a padded position has no packed row; it is embedded only when a pooled exit averages over it
+    auto wanted = [&](int t) __attribute__((always_inline)) { return j0 + t < T && (pooled || __builtin_amdgcn_readlane(m_dst, t) >= 0); };
+    f32x4 xn[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xn[i] = f32x4{0, 0, 0, 0};
+    if (wanted(0)) load_row(0, xn);
+    // not unrolled: eight positions' worth of rows in registers is one wave per SIMD, and this kernel lives on occupancy
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        const bool want = wanted(t);                          // wave-uniform
+        f32x4 x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) x[i] = xn[i];
+        if (t + 1 < 8 && wanted(t + 1)) load_row(t + 1, xn);
+        if (!want) continue;
+        const int dst = __builtin_amdgcn_readlane(m_dst, t);
         wave_layernorm<NV>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // embeddings.LayerNorm
+        if constexpr (POOLED) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc_t[i] += x[i];
+            for (int i = 0; i < NV; ++i) acc_t[i] += x[i];
+        }
         wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);      // layoutlmv3.LayerNorm (after the concat)
+        if constexpr (POOLED) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
+            for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
+        }
         if (dst >= 0) {
             if (a.Xs) wave_store_row_split<NV>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + dst) * H * 4, x, H, lane, a.split_scale, amax);
             else wave_store_row<NV>(a.X + (size_t)(doff + dst) * H, x, H, lane);
         }
     }
     if (a.Xs) split_flag_overflow(amax, a.err_flag);
-    if (a.text_part) block_write_partial<NV>(lds, a.text_part + ((size_t)b * nch + ch) * H, acc_t, H, lane, wave);
-    if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + ch) * H, acc_c, H, lane, wave);
+    if constexpr (POOLED) {
+        if (a.text_part) block_write_partial<NV>(lds, a.text_part + ((size_t)b * nch + ch) * H, acc_t, H, lane, wave);
+        if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + ch) * H, acc_c, H, lane, wave);
+    }
 }
 
 template <int NV>
@@ -437,12 +476,22 @@ void launch_embed_text(const EmbedArgs& a, hipStream_t s) {
     const int grid = a.B * ((a.T + 31) / 32);
     const size_t lds = 4 * (size_t)a.H * sizeof(float);
     const int nv = (a.H + 255) / 256;
+    const bool fast = (a.cs & 3) == 0 && (a.ss & 3) == 0;
+    const bool pooled = a.text_part || a.cat_part;
+#define MMEE_ET(NV_, F_, P_) hipLaunchKernelGGL((embed_text_kernel<NV_, F_, P_>), dim3(grid), dim3(256), lds, s, a)
     switch (nv) {
-        case 1: hipLaunchKernelGGL(embed_text_kernel<1>, dim3(grid), dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL(embed_text_kernel<2>, dim3(grid), dim3(256), lds, s, a); break;
-        case 3: hipLaunchKernelGGL(embed_text_kernel<3>, dim3(grid), dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(embed_text_kernel<4>, dim3(grid), dim3(256), lds, s, a); break;
+        case 1: MMEE_ET(1, false, true); break;      // tiny test models
+        case 2: MMEE_ET(2, false, true); break;
+        case 3:
+            if (fast && pooled) MMEE_ET(3, true, true); else if (fast) MMEE_ET(3, true, false);
+            else if (pooled) MMEE_ET(3, false, true); else MMEE_ET(3, false, false);
+            break;
+        default:
+            if (fast && pooled) MMEE_ET(4, true, true); else if (fast) MMEE_ET(4, true, false);
+            else if (pooled) MMEE_ET(4, false, true); else MMEE_ET(4, false, false);
+            break;
     }
+#undef MMEE_ET
 }
 
 void launch_embed_visual(const EmbedArgs& a, hipStream_t s) {
