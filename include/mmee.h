@@ -62,8 +62,11 @@ enum { MMEE_DT_F32 = 0, MMEE_DT_F16 = 1, MMEE_DT_BF16 = 2 };
 enum {
     MMEE_FLAG_DENSE_ROWS = 1,  /* keep all T text rows per document (pad rows computed, masked as keys) instead of the
                                   ragged layout that drops pad rows; results are identical, this is the A/B switch  */
-    MMEE_FLAG_NO_EXIT = 2      /* dump-all mode: evaluate every exit for every document, nobody leaves early
+    MMEE_FLAG_NO_EXIT = 2,     /* dump-all mode: evaluate every exit for every document, nobody leaves early
                                   (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
+    MMEE_FLAG_WHOLE_LAYERS = 4 /* run every encoder layer whole before its exit decision (what the reference does,
+                                  EE/models/LayoutLMv3.py:757-768) instead of "probe first" (ee_last_layer_plan); results are
+                                  identical bit for bit, this is the A/B switch                                      */
 };
 
 typedef struct ee_handle ee_handle;

@@ -14,6 +14,7 @@ MAX_ENCODER_EXITS = 64
 EXIT_KIND = {"vision_avg": 0, "text_avg": 1, "text_visual_concat": 2}
 FLAG_DENSE_ROWS = 1
 FLAG_NO_EXIT = 2
+FLAG_WHOLE_LAYERS = 4
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _LIB_NAME = "libmmee_hip.so"

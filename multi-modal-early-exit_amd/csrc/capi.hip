@@ -813,7 +813,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     h->layer_qkv_stage.assign(L, -1);
     h->layer_probe_stage.assign(L, -1);
     h->exit_stage.assign(E + 1, 0);
-    static const bool probe_on = [] { const char* e = getenv("MMEE_PROBE"); return !(e && e[0] == '0'); }();   // MMEE_PROBE=0: whole layers (A/B)
+    const bool probe_on = !(flags & MMEE_FLAG_WHOLE_LAYERS);
     bool cls_ready = false;
 
     auto run_head = [&](const HeadW& hw, const float* in, int ld, const int* gather, float* hid, float* out) {

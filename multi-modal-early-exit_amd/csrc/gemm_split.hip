@@ -534,6 +534,12 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
         return;
     }
     const bool use_a = forced == 1;
+    if (a.dbg_noload && forced == 0) {      // timing diagnostics of the default configuration (tools/gemm_split_shapes.py)
+        if (a.out_split && epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true, true>(a, max_m, num_cus, s);
+        else if (a.out_split) launch_split_one<CfgC, EPI_BIAS, true, true>(a, max_m, num_cus, s);
+        else launch_split_one<CfgC, EPI_RESID, false, true>(a, max_m, num_cus, s);
+        return;
+    }
     if (a.dbg_noload) {      // timing diagnostics: only the two shapes the probes use
         if (a.out_split) launch_split_one<CfgA, EPI_GELU, true, true>(a, max_m, num_cus, s);
         else if (use_a) launch_split_one<CfgA, EPI_RESID, false, true>(a, max_m, num_cus, s);

@@ -229,7 +229,10 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
       * a document's early-exit result is BIT-identical to its dump-all result at the exit the policy picks (rows are
         independent in every kernel, so dropping the other documents must not change a single bit);
       * permuting the batch permutes the outputs bit for bit (work queues, compaction and tiling are order-free);
-      * the stage populations are the survivors of the exits, and every document leaves exactly once."""
+      * the stage populations are the survivors of the exits, and every document leaves exactly once;
+      * split precision runs exit layers "probe first" (CLS rows, decision, then the layer's bulk for the documents that stay):
+        the whole-layer run (`whole_layers=True`, what the reference does) gives the same bits, and the layer plan says which
+        rows each layer really processed."""
     import torch
     ee = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp")
     cfg = pkg.ModelConfig.base(EE_config=ee)
@@ -260,9 +263,30 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
     got = _np(out.logits)
     want = _np(full.all_logits)[ex, np.arange(B)]
     assert np.array_equal(got, want), float(np.abs(got - want).max())    # bit-identical to the dump-all rows
-    counts = eng.stage_counts()["docs"]
+    sc = eng.stage_counts()
+    counts = sc["docs"]
     surv = [int((ex >= e).sum()) for e in range(len(counts))]
     assert counts == surv and sum(int((ex == e).sum()) for e in range(conf.shape[0])) == B
+    # probe-first exit layers: which rows each layer processed, and the whole-layer run as the A/B
+    plan = eng.layer_plan()
+    stage_before = [sum(1 for x in ee["exits"] if x <= l) for l in range(cfg.num_hidden_layers)]      # stage entering layer l
+    assert plan["rows_qkv"] == [sc["rows"][st] for st in stage_before]
+    if precision == "split":
+        for l in range(cfg.num_hidden_layers):
+            ends_in_decision = (l + 1) in ee["exits"] or l == cfg.num_hidden_layers - 1
+            assert plan["docs_probe"][l] == (sc["docs"][stage_before[l]] if ends_in_decision else 0)
+            want_rows = 0 if l == cfg.num_hidden_layers - 1 else sc["rows"][stage_before[l] + (1 if (l + 1) in ee["exits"] else 0)]
+            assert plan["rows_main"][l] == want_rows, (l, plan)
+        assert plan["probe_flops"] > 0
+    else:
+        assert plan["docs_probe"] == [0] * cfg.num_hidden_layers and plan["rows_main"] == plan["rows_qkv"]
+    whole = eng.forward(*args, thresholds=thr, whole_layers=True, want_hidden_cls=True)
+    assert eng.layer_plan()["docs_probe"] == [0] * cfg.num_hidden_layers
+    assert np.array_equal(_np(whole.exit_layer), ex) and np.array_equal(_np(whole.logits), got)
+    assert np.array_equal(_np(whole.confidence), _np(out.confidence))
+    hid = eng.forward(*args, thresholds=thr, want_hidden_cls=True)
+    a, b = _np(hid.hidden_cls), _np(whole.hidden_cls)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])   # CLS of every layer, every active document
     # permutation invariance
     perm = np.random.default_rng(7).permutation(B)
     pargs = tuple(a[perm] for a in args)
