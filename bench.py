@@ -53,6 +53,7 @@ def parse():
                          "image-only DiT-base (BEiT), ramp exit head at every layer")
     ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
     ap.add_argument("--whole-layers", action="store_true", help="run exit layers whole before deciding (A/B switch of probe-first)")
+    ap.add_argument("--probe-always", action="store_true", help="probe first at every exit layer (default: chosen per layer)")
     ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
@@ -245,7 +246,7 @@ def main():
         thr = pkg.dist.broadcast_array(thr, 0, device=dev)
 
     def step():
-        return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers)
+        return eng.forward(d_ids, d_am, d_bb, d_px, thresholds=thr, dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers, probe_always=a.probe_always)
 
     def run_local(idx):
         # this rank's shard of the job's documents (global document g = rank + world * i, i = step * B + position): K steps of
@@ -301,7 +302,7 @@ def main():
                    ("BASELINE configs[4]: image-only DiT-base (BEiT, S=197), ramp exit head at every layer (extrapolation: the "
                     "reference defines no DiT exits), per-exit thresholds, synthetic pages, random-init weights"),
                    "docs_per_step_per_gpu": B, "text_len": T, "rows_layout": "dense" if a.dense_rows else "ragged",
-                   "exit_layers": "whole" if a.whole_layers else "probe first",
+                   "exit_layers": "whole" if a.whole_layers else "probe first" if a.probe_always else "probe first where it pays",
                    "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
                    "release_fraction_per_exit": a.release},
         "mean_exit_layer": float(layer_of_exit[exits].mean()), "mean_exit_index": float(exits.mean()),
@@ -366,7 +367,7 @@ def main():
         srows = []
         for batch in feeder:
             o = eng.forward(batch["input_ids"], batch["attention_mask"], batch["bbox"], batch["pixel_values"], thresholds=thr,
-                            dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers)
+                            dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers, probe_always=a.probe_always)
             srows.append(pkg.dist.pack_results(o.logits, o.exit_layer, o.confidence))
         srows = torch.cat(srows, dim=0)
         torch.cuda.synchronize()

@@ -64,9 +64,12 @@ enum {
                                   ragged layout that drops pad rows; results are identical, this is the A/B switch  */
     MMEE_FLAG_NO_EXIT = 2,     /* dump-all mode: evaluate every exit for every document, nobody leaves early
                                   (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
-    MMEE_FLAG_WHOLE_LAYERS = 4 /* run every encoder layer whole before its exit decision (what the reference does,
-                                  EE/models/LayoutLMv3.py:757-768) instead of "probe first" (ee_last_layer_plan); results are
-                                  identical bit for bit, this is the A/B switch                                      */
+    MMEE_FLAG_WHOLE_LAYERS = 4,/* run every encoder layer whole before its exit decision (what the reference does,
+                                  EE/models/LayoutLMv3.py:757-768), never "probe first" (ee_last_layer_plan)          */
+    MMEE_FLAG_PROBE_ALWAYS = 8 /* probe first at every layer that ends in a decision.  With neither flag the choice is made per
+                                  exit layer from the stage populations of the handle's most recent finished forward (a probe
+                                  pays when enough rows leave; the last layer is always probed).  All three give identical
+                                  results bit for bit: the flags only pin the schedule, for A/B runs and tests          */
 };
 
 typedef struct ee_handle ee_handle;

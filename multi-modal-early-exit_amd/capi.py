@@ -15,6 +15,7 @@ EXIT_KIND = {"vision_avg": 0, "text_avg": 1, "text_visual_concat": 2}
 FLAG_DENSE_ROWS = 1
 FLAG_NO_EXIT = 2
 FLAG_WHOLE_LAYERS = 4
+FLAG_PROBE_ALWAYS = 8
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _LIB_NAME = "libmmee_hip.so"

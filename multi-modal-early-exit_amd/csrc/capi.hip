@@ -99,6 +99,11 @@ struct ee_handle {
     bool has_fwd = false;
     // err_flag of the last forward, copied to pinned host memory behind it: the next call reports it without a synchronisation
     int* err_host = nullptr;
+    // stage counts of recent forwards, copied to pinned host memory behind each forward (a ring: the caller may enqueue several
+    // forwards before any has finished).  They only steer a scheduling choice (probe-first or whole exit layers), never a result.
+    struct HistSlot { hipEvent_t done = nullptr; StageCounts* counts = nullptr; int B = 0; bool used = false; };
+    HistSlot hist[4];
+    unsigned fwd_seq = 0;
     // bookkeeping of the last forward
     int last_B = 0, last_T = 0, last_stages = 0;
     std::vector<int> layer_stage;                 // stage whose rows the layer's attention / attention-out / FFN ran on; -1: none (probe only)
@@ -498,6 +503,10 @@ int ee_destroy(ee_handle* h) {
     for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
     if (h->err_host) (void)hipHostFree(h->err_host);
+    for (auto& hs : h->hist) {
+        if (hs.counts) (void)hipHostFree(hs.counts);
+        if (hs.done) (void)hipEventDestroy(hs.done);
+    }
     for (void* q : h->allocs) (void)hipFree(q);
     delete h;
     return 0;
@@ -696,6 +705,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                     (e & mmee::kErrSplitOverflow) ? "split-precision overflow: run this checkpoint with precision \"fp32\"" : "input out of range");
     }
     if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
+    // the most recent thresholded forward that has finished: its stage populations predict this one's (steady streams repeat)
+    const StageCounts* prev = nullptr;
+    int prev_B = 0;
+    for (unsigned k = 1; k <= 4 && !prev; ++k) {
+        const ee_handle::HistSlot& hs = h->hist[(h->fwd_seq - k) & 3];
+        if (hs.used && hipEventQuery(hs.done) == hipSuccess) { prev = hs.counts; prev_B = hs.B; }
+    }
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
     h->next_queue_head = 0;
@@ -1014,7 +1030,18 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         const bool last = l == L - 1;
         // probe first: this layer ends in a decision (an exit head, or the final classifier), split attention kernels, no dump of
         // every layer (the dump keeps every document to the end, so nothing would be saved)
-        const bool probe = probe_on && sp && !no_exit && (exit_here != last);
+        bool probe = probe_on && sp && !no_exit && (exit_here != last);
+        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS) && prev && prev_B > 0 && prev[cur].n_rows > 0) {
+            // An exit layer: the probe pays when the rows it saves (attention, attention-out, FFN of the documents that leave) cost more
+            // than the probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document).
+            // Rates as measured on MI355X; both orders give the same bits, only the time differs.
+            const double scale = (double)B / prev_B;
+            const double rows = prev[cur].n_rows * scale, leave = (prev[cur].n_rows - prev[cur + 1].n_rows) * scale;
+            const double len = (double)prev[cur].sum_len_sq / prev[cur].n_rows;                   // mean keys per query
+            const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I) / 380e12 + 4.0 * len * H / 200e12;
+            const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + 100e-6 + rows * 8.0 * H / 3.6e12;
+            probe = leave * t_row > 1.1 * cost;
+        }
         layer_qkv();
         if (probe) {
             layer_probe();
@@ -1064,6 +1091,19 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
     h->last_gate_heads = out_head_logits || out_head_crit;
     HIP_OK(h, hipMemcpyAsync(h->err_host, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    {
+        ee_handle::HistSlot& hs = h->hist[h->fwd_seq & 3];
+        hs.used = false;
+        if (!no_exit) {                  // a dump keeps every document to the end: it says nothing about the exits
+            if (!hs.done) HIP_OK(h, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+            if (!hs.counts) HIP_OK(h, hipHostMalloc((void**)&hs.counts, sizeof(StageCounts) * (size_t)(E + 2), hipHostMallocDefault));
+            HIP_OK(h, hipMemcpyAsync(hs.counts, h->counts, sizeof(StageCounts) * (size_t)(E + 2), hipMemcpyDeviceToHost, s));
+            HIP_OK(h, hipEventRecord(hs.done, s));
+            hs.B = B;
+            hs.used = true;
+        }
+        ++h->fwd_seq;
+    }
     HIP_OK(h, hipEventRecord(h->fwd_done, s));
     h->last_stream = s; h->has_fwd = true;
     HIP_OK(h, hipGetLastError());

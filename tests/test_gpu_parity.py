@@ -256,7 +256,7 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
         active &= ~(conf[e] > thr[e])
     assert np.abs(conf[:-1] - thr[:-1, None]).min() > 1e-6
     ex_ref, pred_ref, _ = oracle.policy_scan(store, thr)
-    out = eng.forward(*args, thresholds=thr)
+    out = eng.forward(*args, thresholds=thr, probe_always=True)
     ex = _np(out.exit_layer)
     assert np.array_equal(ex, ex_ref)
     assert len(np.unique(ex)) >= 4                                       # the mix really exercises several stages
@@ -284,7 +284,7 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
     assert eng.layer_plan()["docs_probe"] == [0] * cfg.num_hidden_layers
     assert np.array_equal(_np(whole.exit_layer), ex) and np.array_equal(_np(whole.logits), got)
     assert np.array_equal(_np(whole.confidence), _np(out.confidence))
-    hid = eng.forward(*args, thresholds=thr, want_hidden_cls=True)
+    hid = eng.forward(*args, thresholds=thr, want_hidden_cls=True, probe_always=True)
     a, b = _np(hid.hidden_cls), _np(whole.hidden_cls)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])   # CLS of every layer, every active document
     # permutation invariance
