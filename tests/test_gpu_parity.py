@@ -297,6 +297,49 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
     eng.close()
 
 
+def test_exit_layer_schedule_follows_the_last_forward(pkg, oracle):
+    """Split precision decides per exit layer whether to probe first, from the stage populations of the handle's most recent FINISHED
+    thresholded forward (ee_forward flags, include/mmee.h): with many leavers the exit layer is probed, with hardly any it is run whole,
+    the last layer is probed either way, a dump-all run leaves the history alone — and the results are the same bits in every schedule."""
+    ee = dict(exits=[2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=4)
+    W = pkg.synth.make_weights(cfg, seed=11, head_gain=6.0)
+    B = 96
+    docs = pkg.synth.make_documents(cfg, B, seed=5, text_len=128)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=128, precision="split")
+    eng.load_weights(W)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    full = eng.forward(*args, dump_all=True, want_all=True)
+    conf = oracle.softmax64(_np(full.all_logits).astype(np.float64)).max(-1)[0]
+    c = np.sort(conf)
+
+    def gap(k):                                   # a threshold that releases the B - k most confident documents at the exit
+        lo, hi = max(1, k - 2), min(B - 1, k + 2)
+        j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
+        return 0.5 * (c[j - 1] + c[j]), B - j
+
+    thr_many, n_many = gap(B // 2)                # about half of the documents leave at layer 2
+    thr_few, n_few = gap(B - 2)                   # two or so leave
+    first = eng.forward(*args, thresholds=[thr_many, 2.0])          # no thresholded history yet (the dump does not count): probes
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_many]
+    many = eng.forward(*args, thresholds=[thr_many, 2.0])           # history: half leave -> the probe pays
+    torch_sync = eng.stage_counts()
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_many] and torch_sync["docs"] == [B, B - n_many]
+    few = eng.forward(*args, thresholds=[thr_few, 2.0])             # still scheduled from the half-leave forward
+    eng.stage_counts()
+    few2 = eng.forward(*args, thresholds=[thr_few, 2.0])            # history: almost nobody leaves -> layer 2 runs whole, the last layer is probed
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, B - n_few]
+    whole = eng.forward(*args, thresholds=[thr_few, 2.0], whole_layers=True)
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, 0]
+    always = eng.forward(*args, thresholds=[thr_few, 2.0], probe_always=True)
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_few]
+    for a, b in ((first, many), (few, few2), (few, whole), (few, always)):
+        assert np.array_equal(_np(a.exit_layer), _np(b.exit_layer)) and np.array_equal(_np(a.logits), _np(b.logits))
+        assert np.array_equal(_np(a.confidence), _np(b.confidence))
+    assert int((_np(many.exit_layer) == 0).sum()) == n_many and int((_np(few.exit_layer) == 0).sum()) == n_few
+    eng.close()
+
+
 def test_split_precision_edge_batches(pkg, oracle):
     """Split-precision path at the base width on degenerate batches: one document, everybody leaving at the first exit (every
     later stage is empty: M = 0 launches), nobody leaving, short texts; a batch larger than the handle is refused loudly."""
