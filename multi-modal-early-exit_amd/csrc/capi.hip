@@ -444,7 +444,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
             rc |= dev_alloc(h, &h->Ys, rows * H);
             rc |= dev_alloc(h, &h->absmax_dev, 4);
             rc |= dev_alloc(h, &h->cls_f32, Bm * H);
-            if (!beit) {
+            {
                 rc |= dev_alloc(h, &h->Yc, Bm * H);
                 rc |= dev_alloc(h, &h->Ycs, Bm * H);
                 rc |= dev_alloc(h, &h->H1c, Bm * I);
@@ -456,6 +456,8 @@ int ee_create(const ee_config* c, ee_handle** out) {
                     for (size_t i = 0; i < Bm; ++i) io[i] = (int)i;
                     if (hipMemcpy(h->iota, io.data(), sizeof(int) * Bm, hipMemcpyHostToDevice) != hipSuccess) rc = fail(h, "hipMemcpy failed");
                 }
+            }
+            if (!beit) {
                 h->idx_nb = (int)((Tm + Pv + 31) / 32);
                 h->idx_stride = (size_t)h->idx_nb * h->idx_nb * 1024;
                 rc |= dev_alloc(h, &h->pair_idx, Bm * h->idx_stride);
@@ -904,43 +906,114 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         launch_gather_cls((sp && !beit) ? h->Xs : h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls, B, s,
                           (sp && !beit) ? 1.0f / mmee::kSplitScaleX : 0.f);
 
+    // An exit layer: the probe pays when the rows it saves (attention, attention-out, FFN of the documents that leave) cost more than the
+    // probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document), judged from the
+    // stage populations of the last finished forward; no history: probe.  Rates as measured on MI355X; both orders
+    // give the same bits, only the time differs.
+    auto probe_pays = [&]() -> bool {
+        if (!prev || prev_B <= 0 || prev[cur].n_rows <= 0) return true;
+        const double scale = (double)B / prev_B;
+        const double rows = prev[cur].n_rows * scale, leave = (prev[cur].n_rows - prev[cur + 1].n_rows) * scale;
+        const double len = (double)prev[cur].sum_len_sq / prev[cur].n_rows;                   // mean keys per query
+        const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I) / 380e12 + 4.0 * len * H / 200e12;
+        const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + 100e-6 + rows * 8.0 * H / 3.6e12;
+        return leave * t_row > 1.1 * cost;
+    };
     int next_enc = 0;
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
         const int* rows_ptr = &h->counts[cur].n_rows;
         const int* rs = use_row_src ? h->row_src : nullptr;
-        if (beit) {
-            h->layer_stage[l] = h->layer_qkv_stage[l] = cur;
-            // BeitLayer.forward (BEIT:406-444): pre-LN, layer scale.  Z = CTX buffer (LN output / attention output by turns)
-            GemmArgs g{};
+        // ---- BEiT / DiT layer (BEIT:406-444: pre-LN, layer scale), in the same three pieces as the LayoutLMv3 layer below -----------
+        // LN output and attention output take turns in the CTX buffer; the residual stream X / Y stays f32
+        auto beit_qkv = [&]() {
             { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->CTX, rs, rows_ptr, max_rows, H, w.ao_g, w.ao_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
+            GemmArgs g{};
             g.A = h->CTX; g.lda = H; g.W = sp ? w.qkv_s : w.qkv_w; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
             g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleQKV;
             g.m_ptr = rows_ptr; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
+            h->layer_qkv_stage[l] = cur;
+        };
+        auto beit_attn_args = [&]() {
             AttnArgs at{};
             at.qkv = h->QKV; at.ld = 3 * H; at.ctx = h->CTX; at.ldc = H; at.meta = h->meta[meta_cur]; at.doc_off = S_doc_off(cur);
             at.counts = &h->counts[cur]; at.t1 = h->t1; at.tx = h->tx; at.ty = h->ty; at.n1 = h->n1; at.c1 = h->c1; at.n2 = h->n2; at.c2 = h->c2;
             at.H = H; at.heads = c.num_attention_heads; at.max_len = max_len; at.item_counter = next_head();
             at.ctx_split = sp ? 1 : 0; at.err_flag = h->err_flag; at.ctx_scale = mmee::kSplitScaleCtx; at.qkv_scale = mmee::kSplitScaleQKV;
             fill_idx(at);
-        { ProfScope ps(h, P_ATTN, s); if (sp && use_idx && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s); else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s); else launch_attention_f32(at, B, cus, s); }
-            g = GemmArgs{};      // Y = X + lambda_1 * (ctx Wo^T + bo)
-            g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = rs;
+            return at;
+        };
+        auto beit_run_attn = [&](const AttnArgs& at) {
+            if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s);
+            else launch_attention_f32(at, B, cus, s);
+        };
+        auto beit_rest = [&](const int* x_rows, const int* qkv_off) {
+            const int* rp = &h->counts[cur].n_rows;
+            AttnArgs at = beit_attn_args();
+            at.qkv_doc_off = qkv_off;
+            { ProfScope ps(h, P_ATTN, s); beit_run_attn(at); }
+            GemmArgs g{};        // Y = X + lambda_1 * (ctx Wo^T + bo)
+            g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = h->X; g.ldr = H; g.resid_row_src = x_rows;
             g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
-            g.col_scale = w.lam1; g.m_ptr = rows_ptr; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            g.col_scale = w.lam1; g.m_ptr = rp; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
-            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->CTX, nullptr, rows_ptr, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
+            { ProfScope ps(h, P_LN, s); launch_ln_rows(h->Y, sp ? nullptr : h->CTX, nullptr, rp, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->CTX : nullptr, mmee::kSplitScaleX, h->err_flag); }
             g = GemmArgs{};
-            g.A = h->CTX; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rows_ptr; g.N = I; g.K = H; g.scale = 1.f;
+            g.A = h->CTX; g.lda = H; g.W = sp ? w.f1_s : w.f1_w; g.bias = w.f1_b; g.C = h->H1; g.ldc = I; g.m_ptr = rp; g.N = I; g.K = H; g.scale = 1.f;
             g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = sp ? 1 : 0; g.out_scale = mmee::kSplitScaleH1;
             g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GUP, s); run_gemm(g, EPI_GELU); }
             g = GemmArgs{};      // X = Y + lambda_2 * (h1 W2^T + b2)
             g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = h->Y; g.ldr = H; g.col_scale = w.lam2;
             g.alpha = w.f2_inv / mmee::kSplitScaleH1;
-            g.m_ptr = rows_ptr; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
+            g.m_ptr = rp; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
+            h->layer_stage[l] = cur;
+        };
+        // CLS probe of a BEiT layer (split precision): the exit head reads the CLS row of X (f32), which lands in Xc
+        auto beit_probe = [&]() {
+            ProfScope ps(h, P_PROBE, s);
+            const int* nd = &h->counts[cur].n_docs;
+            AttnArgs at = beit_attn_args();
+            at.q_limit = 32; at.max_len = max_len < 32 ? max_len : 32;
+            beit_run_attn(at);
+            GemmArgs g{};
+            g.A = h->CTX; g.lda = H; g.row_src = S_doc_off(cur); g.W = w.ao_s; g.bias = w.ao_b; g.C = h->Yc; g.ldc = H;
+            g.resid = h->X; g.ldr = H; g.resid_row_src = x_phys; g.col_scale = w.lam1;
+            g.alpha = w.ao_inv / mmee::kSplitScaleCtx; g.probe = 1;
+            g.m_ptr = nd; g.N = H; g.K = H; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+            launch_gemm_split(g, EPI_RESID, B, cus, s);
+            launch_ln_rows(h->Yc, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Ycs, mmee::kSplitScaleX, h->err_flag);
+            g = GemmArgs{};
+            g.A = h->Ycs; g.lda = H; g.W = w.f1_s; g.bias = w.f1_b; g.C = h->H1c; g.ldc = I; g.m_ptr = nd; g.N = I; g.K = H; g.scale = 1.f;
+            g.prio_mode = 1; g.err_flag = h->err_flag; g.probe = 1;
+            g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = 1; g.out_scale = mmee::kSplitScaleH1;
+            launch_gemm_split(g, EPI_GELU, B, cus, s);
+            g = GemmArgs{};
+            g.A = h->H1c; g.lda = I; g.W = w.f2_s; g.bias = w.f2_b; g.C = h->Xc; g.ldc = H; g.resid = h->Yc; g.ldr = H; g.col_scale = w.lam2;
+            g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.probe = 1;
+            g.m_ptr = nd; g.N = H; g.K = I; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+            launch_gemm_split(g, EPI_RESID, B, cus, s);
+            h->layer_probe_stage[l] = cur;
+        };
+        if (beit) {
+            const bool exit_here = next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1;
+            // the mean-pooled final classifier reads every row of the last layer: only exit layers before it can be probed
+            bool probe = probe_on && sp && !no_exit && exit_here && l != L - 1;
+            if (probe && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = probe_pays();
+            beit_qkv();
+            if (probe) {
+                beit_probe();
+                if (out_hidden_cls) launch_gather_cls(h->Xc, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s);
+                run_exit(&h->enc_heads[next_enc], h->Xc, H, nullptr, false);      // compacts: `cur` is now the stage of the documents that stay
+                ++next_enc;
+                beit_rest(h->row_src, S_meta_src(cur));
+                x_phys = S_doc_off(cur);
+                use_row_src = false;
+                continue;
+            }
+            beit_rest(rs, nullptr);
         } else {
         // ---- LayoutLMv3 layer (HF:485-512), in three pieces so that an exit layer can decide BEFORE its bulk runs ----------------
         // Q | K | V projection of every row of the stage, Q pre-divided by sqrt(d) (HF:263)
@@ -1031,17 +1104,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // probe first: this layer ends in a decision (an exit head, or the final classifier), split attention kernels, no dump of
         // every layer (the dump keeps every document to the end, so nothing would be saved)
         bool probe = probe_on && sp && !no_exit && (exit_here != last);
-        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS) && prev && prev_B > 0 && prev[cur].n_rows > 0) {
-            // An exit layer: the probe pays when the rows it saves (attention, attention-out, FFN of the documents that leave) cost more
-            // than the probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document).
-            // Rates as measured on MI355X; both orders give the same bits, only the time differs.
-            const double scale = (double)B / prev_B;
-            const double rows = prev[cur].n_rows * scale, leave = (prev[cur].n_rows - prev[cur + 1].n_rows) * scale;
-            const double len = (double)prev[cur].sum_len_sq / prev[cur].n_rows;                   // mean keys per query
-            const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I) / 380e12 + 4.0 * len * H / 200e12;
-            const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + 100e-6 + rows * 8.0 * H / 3.6e12;
-            probe = leave * t_row > 1.1 * cost;
-        }
+        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = probe_pays();
         layer_qkv();
         if (probe) {
             layer_probe();

@@ -149,6 +149,43 @@ def test_dit_image_only_variant_matches_golden(pkg, oracle, precision):
         eng.close()
 
 
+def test_dit_probe_first_gives_the_same_bits(pkg, oracle):
+    """Image-only DiT-base in split precision: exit layers probed first (CLS row of the pre-LN layer, decision, the rest for the documents
+    that stay) against whole layers and against the dump-all rows — bit for bit; the mean-pooled last layer is never probed."""
+    ee = dict(exits=[1, 2, 3], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+    cfg = pkg.ModelConfig.dit_base(EE_config=ee, num_hidden_layers=4)
+    W = pkg.synth.make_weights_beit(cfg, seed=21)
+    B = 80
+    pix = pkg.synth.make_documents(cfg, B, seed=3, text_len=8)["pixel_values"]
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, precision="split")
+    eng.load_weights(W)
+    full = eng.forward(pixel_values=pix, dump_all=True, want_all=True, want_hidden_cls=True)
+    store = _np(full.all_logits).astype(np.float64)
+    conf = oracle.softmax64(store).max(-1)
+    thr = np.full(conf.shape[0], 2.0)
+    active = np.ones(B, dtype=bool)
+    for e in range(conf.shape[0] - 1):                                   # release about a third of the arrivals at every exit, in a gap
+        c = np.sort(conf[e, active])
+        k = int(0.66 * len(c))
+        lo, hi = max(1, k - 2), min(len(c) - 1, k + 2)
+        j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
+        thr[e] = 0.5 * (c[j - 1] + c[j])
+        active &= ~(conf[e] > thr[e])
+    ex_ref, _, _ = oracle.policy_scan(store, thr)
+    probed = eng.forward(pixel_values=pix, thresholds=thr, probe_always=True, want_hidden_cls=True)
+    sc, plan = eng.stage_counts(), eng.layer_plan()
+    assert plan["docs_probe"] == [sc["docs"][0], sc["docs"][1], sc["docs"][2], 0] and plan["rows_main"] == [sc["rows"][1], sc["rows"][2], sc["rows"][3], sc["rows"][3]]
+    whole = eng.forward(pixel_values=pix, thresholds=thr, whole_layers=True, want_hidden_cls=True)
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, 0]
+    ex = _np(probed.exit_layer)
+    assert np.array_equal(ex, ex_ref) and len(np.unique(ex)) >= 3
+    assert np.array_equal(_np(whole.exit_layer), ex) and np.array_equal(_np(whole.logits), _np(probed.logits))
+    assert np.array_equal(_np(probed.logits), _np(full.all_logits)[ex, np.arange(B)])          # == the dump-all rows
+    a, b = _np(probed.hidden_cls), _np(whole.hidden_cls)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+    eng.close()
+
+
 def _decode_split(buf, n, scale):
     import torch
     h = buf.view(torch.float16).view(buf.shape[0], n // 16, 2, 16)      # 64-byte groups [hi 16 | lo 16]
