@@ -1,0 +1,74 @@
+"""Randomised cross-check of the exit-layer schedules (GPU box only): for random shapes / exit sets / strategies / thresholds the
+probe-first, whole-layer and automatic schedules and the dump-all rows must agree bit for bit.  Not a test (minutes); run after touching
+the layer loop of csrc/capi.hip:  python tools/fuzz_schedules.py [n_cases]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("multi-modal-early-exit_amd")
+_np = lambda t: t.detach().cpu().numpy()
+
+
+def softmax64(x):
+    x = x.astype(np.float64)
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def one(case, rng):
+    L = int(rng.integers(2, 6))
+    exits = sorted(rng.choice(np.arange(1, L + 1), size=int(rng.integers(1, L + 1)), replace=False).tolist())
+    strat = ["ramp", "gate"][int(rng.integers(0, 2))]
+    emb = [[], ["vision_avg"], ["text_avg", "text_visual_concat"]][int(rng.integers(0, 3))]
+    ee = dict(exits=emb + exits, encoder_layer_strategy=strat)
+    H = [256, 768][int(rng.integers(0, 2))]
+    cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=L, hidden_size=H, intermediate_size=4 * H if H == 768 else 512,
+                               num_attention_heads=H // 64, coordinate_size=40 if H == 256 else 128, shape_size=48 if H == 256 else 128)
+    B = int(rng.choice([1, 5, 33, 96]))
+    T = int(rng.choice([16, 130, 512]))
+    W = pkg.synth.make_weights(cfg, seed=int(rng.integers(1, 1 << 30)), head_gain=6.0)
+    docs = pkg.synth.make_documents(cfg, B, seed=int(rng.integers(1, 1 << 30)), text_len=T, min_words=1)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision="split")
+    eng.load_weights(W)
+    E1 = len(ee["exits"]) + 1
+    temps = rng.uniform(0.5, 3.0, size=E1) if rng.integers(0, 2) else None
+    dense = bool(rng.integers(0, 2))
+    full = eng.forward(*args, dump_all=True, want_all=True, temperatures=temps, dense_rows=dense)
+    store = _np(full.all_logits).astype(np.float64)
+    conf = softmax64(store / (temps[:, None, None] if temps is not None else 1.0)).max(-1)
+    thr = np.full(E1, 2.0)
+    active = np.ones(B, dtype=bool)
+    for e in range(E1 - 1):
+        c = np.sort(conf[e, active])
+        if len(c) < 2:
+            continue
+        j = int(rng.integers(1, len(c)))
+        thr[e] = 0.5 * (c[j - 1] + c[j])
+        if c[j] - c[j - 1] < 1e-6:
+            thr[e] = 2.0
+        active &= ~(conf[e] > thr[e])
+    outs = []
+    for kw in (dict(probe_always=True), dict(whole_layers=True), dict(), dict()):
+        o = eng.forward(*args, thresholds=thr, temperatures=temps, dense_rows=dense, **kw)
+        eng.check()
+        outs.append((_np(o.exit_layer), _np(o.logits), _np(o.confidence), eng.layer_plan()["docs_probe"]))
+    ex = outs[0][0]
+    want = _np(full.all_logits)[ex, np.arange(B)]
+    ok = all(np.array_equal(o[0], ex) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) for o in outs)
+    ok = ok and np.array_equal(outs[0][1], want)
+    print(f"case {case}: L={L} H={H} exits={ee['exits']} {strat} B={B} T={T} dense={dense} temps={temps is not None} "
+          f"left at {np.bincount(ex, minlength=E1).tolist()} probes {outs[0][3]} auto {outs[3][3]}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    eng.close()
+    return ok
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    rng = np.random.default_rng(2026)
+    bad = sum(not one(i, rng) for i in range(n))
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
