@@ -159,6 +159,14 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
 int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int32_t* docs_probe, int32_t cap, double* probe_flops,
                        void* stream);
 
+/* Pin the exit-layer schedule.  By default a layer that ends in a decision is probed first only where that pays, judged from the stage
+ * populations of the handle's most recent FINISHED forward -- which forward that is depends on timing, so two runs of the same inputs
+ * may schedule differently (same results bit for bit, different launch sequence and time).  enabled != 0: bit l of `mask` says whether
+ * encoder layer l (0-based) is probed first; layers without an exit ignore their bit, the last layer is always probed, and
+ * MMEE_FLAG_WHOLE_LAYERS / MMEE_FLAG_PROBE_ALWAYS still override.  enabled == 0: back to the default.  Benchmarks and profiles pin the
+ * plan of a warm-up forward (ee_last_layer_plan: docs_probe[l] > 0) so that every measured step runs the same launches. */
+int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask);
+
 /*
  * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]
  * (global threshold: repeat it).  exits dev int32 (N,), predictions dev double (N,K), confidence dev double (N,) or

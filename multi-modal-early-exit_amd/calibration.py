@@ -65,8 +65,9 @@ def expected_calibration_error(references, predictions, n_bins: int = None, sche
 
 def fit_temperatures(logits, labels, max_iter: int = 100, device=None, with_ece: bool = True) -> Dict[str, np.ndarray]:
     """``logits`` (E1,N,K) validation logits (numpy / torch, evaluated as float64), ``labels`` (N,).  Returns numpy arrays
-    ``temperature``, ``nll``, ``accuracy``, ``average_confidence``, ``ece`` (each (E1,); accuracy / confidence / ECE AFTER scaling,
-    as EE/eval.py:313-337 records them) and ``iterations``."""
+    ``temperature``, ``nll``, ``accuracy``, ``average_confidence``, ``ece`` (each (E1,); accuracy / confidence / ECE of the SCALED
+    input logits — the reference records these three for the scaled TEST logits instead, EE/eval.py:321-337: see ``calibrate``) and
+    ``iterations``."""
     lib = capi.load()
     dev = _require_torch_cuda(device)
     to = lambda x, dt: (torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x).to(dev, dt).contiguous()
@@ -94,16 +95,42 @@ def fit_temperatures(logits, labels, max_iter: int = 100, device=None, with_ece:
     return res
 
 
-def calibrate(validation_logits, validation_references, test_logits, device=None):
+def calibrate(validation_logits, validation_references, test_logits, device=None, metrics_on: str = "validation"):
     """The loop of ``calibrate()`` (EE/eval.py:277-346) without its file cache: one temperature per exit fitted on the
     validation logits, the test logits divided by it, and ``calibration_metrics`` = {ece, accuracy, temperature,
     average_confidence} (lists, one entry per exit) — the dictionary ``Policy.accuracy_calibration_heuristic`` reads
-    (EE/policy.py:59-79).  Metrics are those of the scaled VALIDATION logits.  Returns (calibrated_test_logits, metrics)."""
-    fit = fit_temperatures(validation_logits, validation_references, device=device)
+    (EE/policy.py:59-79).  Returns (calibrated_test_logits, metrics).
+
+    ``metrics_on`` says which logits the three metrics are taken from:
+
+    * ``"validation"`` (default, a DEVIATION from the reference): the scaled VALIDATION logits against the validation references —
+      the set the temperatures were fitted on and the labels belong to.
+    * ``"reference"``: exactly what EE/eval.py:321-337 computes — ``ece_logits(validation_references, calibrated_logits[i])``,
+      ``softmax(calibrated_logits[i]).max(-1).mean()`` and ``mean(calibrated_logits[i].argmax(-1) == validation_references)`` with
+      ``calibrated_logits[i]`` the scaled TEST logits, i.e. test predictions scored against validation labels.  That only runs
+      when both sets have the same number of samples (it raises otherwise, as numpy does in the reference) and only means
+      something when they are the same samples; the thresholds the heuristic derives differ between the two modes.
+    """
+    if metrics_on not in ("validation", "reference"):
+        raise ValueError('metrics_on must be "validation" or "reference"')
+    fit = fit_temperatures(validation_logits, validation_references, device=device, with_ece=metrics_on == "validation")
     T = fit["temperature"]
     cal = np.asarray(test_logits, dtype=np.float64) / T[:, None, None]
-    metrics = {"ece": [float(v) for v in fit["ece"]], "accuracy": [float(v) for v in fit["accuracy"]],
-               "temperature": [float(v) for v in T], "average_confidence": [float(v) for v in fit["average_confidence"]]}
+    if metrics_on == "reference":
+        refs = np.asarray(validation_references).reshape(-1)
+        if cal.shape[1] != refs.shape[0]:
+            raise ValueError(f"metrics_on='reference' scores the {cal.shape[1]} scaled test logits against the {refs.shape[0]} validation "
+                             "references (EE/eval.py:327-337): the two sets must have the same length")
+        z = cal - cal.max(-1, keepdims=True)
+        sm = np.exp(z)
+        sm /= sm.sum(-1, keepdims=True)
+        ece = [expected_calibration_error(refs, cal[e]) for e in range(cal.shape[0])]
+        acc = [float(np.mean(cal[e].argmax(-1) == refs)) for e in range(cal.shape[0])]
+        conf = [float(sm[e].max(-1).mean()) for e in range(cal.shape[0])]
+    else:
+        ece, acc, conf = fit["ece"], fit["accuracy"], fit["average_confidence"]
+    metrics = {"ece": [float(v) for v in ece], "accuracy": [float(v) for v in acc],
+               "temperature": [float(v) for v in T], "average_confidence": [float(v) for v in conf]}
     return cal, metrics
 
 

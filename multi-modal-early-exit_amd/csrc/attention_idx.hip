@@ -130,8 +130,8 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 // COUNTED (a tile never waits for a DMA it does not need yet), and the index words are asm loads issued right behind the barrier and consumed
 // after the Q K^T MFMAs of the same tile (the bias is then added to the finished scores instead of initialising the accumulator): no
 // compiler-visible vector load is in flight beside the DMA, whose completion hipcc would otherwise wait for at the load's first use.
-template <int MODE, int RING>
-__global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
+template <int MODE, int RING, bool PF, int WPS = WGS>
+__global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -442,36 +442,48 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             // ---- 3-deep ring, counted waits ----------------------------------------------------------------------------------------------
             const unsigned long long ib0 = (unsigned long long)(size_t)idx_base;
             const unsigned ivoff = 16u * (unsigned)lane;
+            const bool want_idx = wave_active && has_bias && !(MODE == 2 && (dbg & (1 | 32)));
+            // index words of one key tile: four asm loads (hand-counted, see above).  PF: the registers are carried around the loop (the words
+            // of tile kt + 1 are fetched as soon as the lookups of tile kt have consumed the registers, a whole softmax + P V + barrier + Q K^T
+            // ahead of their use), so they are read-write operands: input and output are then ONE register by construction and the loop's
+            // back edge needs no copy (a copy in front of the wait would read words that have not landed).
+            u32x4 iw0 = {0u, 0u, 0u, 0u}, iw1 = iw0, iw2 = iw0, iw3 = iw0;
+            auto issue_idx = [&](int kt) __attribute__((always_inline)) {
+                const unsigned long long ib = sgpr64(ib0 + (unsigned long long)kt * 4096ull);
+                // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
+                // states, and nothing inside an asm string is padded by the compiler)
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                             "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                             : "+v"(iw0), "+v"(iw1), "+v"(iw2), "+v"(iw3)
+                             : "v"(ivoff), "s"(ib)
+                             : "memory");
+            };
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
             if (n_kt > 1) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) issue_kv(1, 1, jj);
             }
+            if (PF && want_idx) issue_idx(0);
             STAMP(6, tprev)
             int slot = 0;
             for (int kt = 0; kt < n_kt; ++kt) {
                 const bool more1 = kt + 1 < n_kt, more2 = kt + 2 < n_kt;
-                // tile kt has landed: everything but the (up to) four youngest operations = the pieces of tile kt + 1 is complete; then the
-                // barrier: everyone's pieces have, and everyone is done with tile kt - 1, whose slot tile kt + 2 goes into
-                if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                STAMP(0, tprev)
-                // this tile's index words: asm loads issued in front of the barrier (its wait covers part of their latency) and BEFORE the DMA
-                // pieces of tile kt + 2, so that the counted wait behind the Q K^T MFMAs covers them
-                u32x4 iw0, iw1, iw2, iw3;
-                const bool want_idx = wave_active && has_bias && !(MODE == 2 && (dbg & (1 | 32)));
-                if (want_idx) {
-                    const unsigned long long ib = sgpr64(ib0 + (unsigned long long)kt * 4096ull);
-                    // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
-                    // states, and nothing inside an asm string is padded by the compiler)
-                    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
-                                 : "=&v"(iw0), "=&v"(iw1), "=&v"(iw2), "=&v"(iw3)
-                                 : "v"(ivoff), "s"(ib)
-                                 : "memory");
+                // tile kt has landed: everything but the youngest operations -- the four pieces of tile kt + 1 and (PF) the four index loads
+                // of this tile, issued after them -- is complete; then the barrier: everyone's pieces have, and everyone is done with tile
+                // kt - 1, whose slot tile kt + 2 goes into
+                if (PF && want_idx) {
+                    if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                asm volatile("s_barrier" ::: "memory");
+                STAMP(0, tprev)
+                // not PF: this tile's index words are issued in front of the barrier (its wait covers part of their latency) and BEFORE the DMA
+                // pieces of tile kt + 2, so that the counted wait behind the Q K^T MFMAs covers them
+                if (!PF && want_idx) issue_idx(kt);
+                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");      // 64: no barrier (timing variant: races)
                 STAMP(7, tprev)
                 const int slot2 = slot == 0 ? 2 : slot - 1;       // (slot + 2) % 3
                 if (!wave_active) {
@@ -498,10 +510,13 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                         khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
                         kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
                     }
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
+                    if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
+                    else asm volatile("" :: "v"(kl), "v"(kh));
                     if (more2) issue_kv(kt + 2, slot2, stp);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                    if (!(MODE == 2 && (dbg & 128))) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                    }
                     kh = khn;
                     kl = kln;
                     __builtin_amdgcn_sched_barrier(0);
@@ -526,6 +541,11 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                             const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
                             s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
                         }
+                    }
+                    if (PF && more1) {               // the registers are free: fetch the next tile's words under this tile's softmax and P V
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_idx(kt + 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (!has_bias && k0 + KT > len) {
 #pragma unroll
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             }
         }
     }
-    if (a.ctx_split) split_flag_overflow(amax, a.err_flag);
+    if (a.ctx_split && MODE != 2) split_flag_overflow(amax, a.err_flag);      // the timing variants compute garbage by design
     if (DIAG && stamps && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(stamps + i, ph[i]);
@@ -586,42 +606,54 @@ bool attention_idx_supports(const AttnArgs& a) {
 }
 
 // a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked
-template <int RING>
+template <int RING, bool PF, int WPS = WGS>
 static void launch_idx_ring(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
     constexpr int lds = OFF_STAGE + RING * STAGE_BYTES;
-    static_assert(WGS * lds <= 160 * 1024, "LDS budget");
+    static_assert(WPS * lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef MMEE_DIAG
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#endif
         attr_set = true;
     }
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
-    int grid = WGS * num_cus;
+    int grid = WPS * num_cus;
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
-    if (stamps) hipLaunchKernelGGL((attention_idx_kernel<1, RING>), dim3(grid), dim3(256), lds, s, a, stamps, 0);
-    else if (dbg) hipLaunchKernelGGL((attention_idx_kernel<2, RING>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, dbg);
-    else hipLaunchKernelGGL((attention_idx_kernel<0, RING>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, 0);
+#ifdef MMEE_DIAG
+    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, dbg); return; }
+#endif
+    (void)stamps; (void)dbg;
+    hipLaunchKernelGGL((attention_idx_kernel<0, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, 0);
 }
 
-// a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
-// MMEE_ATTN_RING=2 selects the double-buffered form (A/B switch); default: 3-deep ring with counted waits.
+// The release library runs ONE form: 3-deep ring, index words prefetched a tile ahead.  The diagnostic library (make diag, -DMMEE_DIAG)
+// also carries the stamped build (MMEE_ATTN_STAMPS=1), the timing variants (MMEE_ATTN_DBG=<bits>, wrong results), the double-buffered
+// ring (MMEE_ATTN_RING=2) and the form without index prefetch (MMEE_ATTN_PF=0) for A/B measurements.
 void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
-    // MMEE_ATTN_STAMPS=1 (diagnostic): stamped build, phase sums readable through ee_debug_attn_stamps
+#ifdef MMEE_DIAG
     static unsigned long long* stamps = [] {
-        const char* e = getenv("MMEE_ATTN_STAMPS");
         unsigned long long* p = nullptr;
-        if (e && e[0] == '1' && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
+        if (diag_env_int("MMEE_ATTN_STAMPS", 0) == 1 && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
         return p;
     }();
-    static const int dbg = [] { const char* e = getenv("MMEE_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing variants (wrong results)
-    static const int ring = [] { const char* e = getenv("MMEE_ATTN_RING"); return (e && e[0] == '2') ? 2 : 3; }();
+    static const int dbg = diag_env_int("MMEE_ATTN_DBG", 0);
+    static const int ring = diag_env_int("MMEE_ATTN_RING", 3);
+    static const int pf = diag_env_int("MMEE_ATTN_PF", 1);
     g_attn_idx_stamps = stamps;
-    if (ring == 3) launch_idx_ring<3>(a, max_docs, num_cus, stamps, dbg, s);
-    else launch_idx_ring<2>(a, max_docs, num_cus, stamps, dbg, s);
+    static const int wps = diag_env_int("MMEE_ATTN_WPS", 3);       // 2: two workgroups per CU (256 VGPRs per wave), occupancy A/B
+    if (ring == 2) { launch_idx_ring<2, false>(a, max_docs, num_cus, stamps, dbg, s); return; }
+    if (wps == 2) { launch_idx_ring<3, true, 2>(a, max_docs, num_cus, stamps, dbg, s); return; }
+    if (!pf) { launch_idx_ring<3, false>(a, max_docs, num_cus, stamps, dbg, s); return; }
+    launch_idx_ring<3, true>(a, max_docs, num_cus, stamps, dbg, s);
+#else
+    launch_idx_ring<3, true>(a, max_docs, num_cus, nullptr, 0, s);
+#endif
 }
 
 }  // namespace mmee

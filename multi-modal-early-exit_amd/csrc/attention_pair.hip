@@ -488,8 +488,10 @@ static void launch_pair_hp(const AttnArgs& a, int max_docs, int num_cus, int r1,
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<HP>::BYTES);
+#ifdef MMEE_DIAG
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<HP>::BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<HP>::BYTES);
+#endif
         attr_set = true;
     }
     const int qtiles = (a.max_len + QT - 1) / QT;
@@ -498,9 +500,12 @@ static void launch_pair_hp(const AttnArgs& a, int max_docs, int num_cus, int r1,
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
     const size_t lds = Lds<HP>::BYTES;
-    if (stamps) hipLaunchKernelGGL((attention_pair_kernel<HP, 1>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, stamps, 0);
-    else if (dbg) hipLaunchKernelGGL((attention_pair_kernel<HP, 2>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, (unsigned long long*)nullptr, dbg);
-    else hipLaunchKernelGGL((attention_pair_kernel<HP, 0>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, (unsigned long long*)nullptr, 0);
+#ifdef MMEE_DIAG      // stamped build and timing variants (wrong results): diagnostic library only
+    if (stamps) { hipLaunchKernelGGL((attention_pair_kernel<HP, 1>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_pair_kernel<HP, 2>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, (unsigned long long*)nullptr, dbg); return; }
+#endif
+    (void)stamps; (void)dbg;
+    hipLaunchKernelGGL((attention_pair_kernel<HP, 0>), dim3(grid), dim3(256), lds, s, a, r1, r2, any_masked, (unsigned long long*)nullptr, 0);
 }
 
 // max_rel_pos / max_rel_2d_pos: the distances at which the 1D / 2D buckets saturate (HF:392-413); the tables are clamped there.
@@ -508,15 +513,15 @@ static void launch_pair_hp(const AttnArgs& a, int max_docs, int num_cus, int r1,
 // last key tile is always masked.  MMEE_ATTN_HP=1 / 2 picks the heads per work item (A/B switch; 2 needs an even head count).
 void launch_attention_pair(const AttnArgs& a, int max_docs, int num_cus, int max_rel_pos, int max_rel_2d_pos, int any_masked, hipStream_t s) {
     const int r1 = max_rel_pos < a.c1 ? max_rel_pos : a.c1, r2 = max_rel_2d_pos < a.c2 ? max_rel_2d_pos : a.c2;
-    // MMEE_ATTN_STAMPS=1 (diagnostic): stamped build, phase sums readable through ee_debug_attn_stamps
+    // diagnostic library only (diag_env_int reads nothing in the release library): MMEE_ATTN_STAMPS=1 stamped build, phase sums readable
+    // through ee_debug_attn_stamps; MMEE_ATTN_DBG timing variants (wrong results); MMEE_ATTN_HP heads per work item
     static unsigned long long* stamps = [] {
-        const char* e = getenv("MMEE_ATTN_STAMPS");
         unsigned long long* p = nullptr;
-        if (e && e[0] == '1' && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
+        if (diag_env_int("MMEE_ATTN_STAMPS", 0) == 1 && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
         return p;
     }();
-    static const int dbg = [] { const char* e = getenv("MMEE_ATTN_DBG"); return e ? atoi(e) : 0; }();   // timing variants (wrong results)
-    static const int hp_env = [] { const char* e = getenv("MMEE_ATTN_HP"); return e ? atoi(e) : 0; }();
+    static const int dbg = diag_env_int("MMEE_ATTN_DBG", 0);
+    static const int hp_env = diag_env_int("MMEE_ATTN_HP", 0);
     int hp = hp_env == 1 || hp_env == 2 ? hp_env : kDefaultHP;
     if (a.heads % 2) hp = 1;
     g_attn_pair_stamps = stamps;

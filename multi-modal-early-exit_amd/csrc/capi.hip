@@ -97,8 +97,14 @@ struct ee_handle {
     hipEvent_t fwd_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_fwd = false;
-    // err_flag of the last forward, copied to pinned host memory behind it: the next call reports it without a synchronisation
-    int* err_host = nullptr;
+    // err_flag of every forward, copied to a pinned host word of its own behind it (a ring: the caller may enqueue several forwards before
+    // any has finished).  A later call reports the oldest unreported error of a FINISHED forward without synchronising; a slot is only
+    // reused after its forward has been waited for and checked, so no error is ever overwritten unseen.
+    struct ErrSlot { hipEvent_t done = nullptr; bool pending = false; };
+    static constexpr int kErrSlots = 8;
+    ErrSlot errs[kErrSlots];
+    int* err_host = nullptr;                      // [kErrSlots] pinned
+    unsigned err_seq = 0;                         // forwards enqueued so far
     // stage counts of recent forwards, copied to pinned host memory behind each forward (a ring: the caller may enqueue several
     // forwards before any has finished).  They only steer a scheduling choice (probe-first or whole exit layers), never a result.
     struct HistSlot { hipEvent_t done = nullptr; StageCounts* counts = nullptr; int B = 0; bool used = false; };
@@ -112,6 +118,8 @@ struct ee_handle {
     std::vector<int> exit_stage;
     uint32_t last_flags = 0;
     bool last_gate_heads = true;                  // gate strategy: were the 2-way gate heads evaluated in the last forward
+    bool mask_on = false;                         // ee_set_probe_mask: the exit-layer schedule is pinned
+    uint64_t probe_mask = 0;
 };
 
 namespace {
@@ -132,6 +140,40 @@ int fail(ee_handle* h, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) return fail(h, "%s failed: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
+
+// Error flags of forwards that were enqueued earlier and not reported yet, oldest first.  wait = false: only forwards that have finished
+// (stops at the first one still running: one handle's forwards finish in order); wait = true: waits for each.  all = false: returns at
+// the first forward with flags (the others stay pending); all = true: ORs every pending forward's flags.
+int take_errors(ee_handle* h, bool wait, bool all) {
+    if (!h->err_host) return 0;
+    int acc = 0;
+    for (int i = ee_handle::kErrSlots; i >= 1; --i) {
+        if ((unsigned)i > h->err_seq) continue;
+        const int k = (int)((h->err_seq - (unsigned)i) % ee_handle::kErrSlots);
+        ee_handle::ErrSlot& es = h->errs[k];
+        if (!es.pending) continue;
+        if (wait) (void)hipEventSynchronize(es.done);
+        else if (hipEventQuery(es.done) != hipSuccess) break;
+        es.pending = false;
+        acc |= h->err_host[k];
+        h->err_host[k] = 0;
+        if (acc && !all) break;
+    }
+    return acc;
+}
+
+int report_errors(ee_handle* h, int err, const char* whose) {
+    if (err & 32)
+        return fail(h, "ee_forward: internal error in %s (flags %d): the attention kernel found its dynamic LDS region away from address 0", whose, err);
+    if (err & mmee::kErrSplitOverflow)
+        return fail(h, "ee_forward: split-precision overflow in %s (flags %d): an activation left the range of the split-f16 planes (|LayerNorm out|, "
+                       "|Q/sqrt(d)|, |K|, |V|, |GELU out|, |pixel_values| <= 3750, |attention context| <= 937) and was clamped, so its results are WRONG; "
+                       "run this checkpoint with precision \"fp32\"", whose, err);
+    if (err)
+        return fail(h, "ee_forward: input out of range in %s (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id, 8 = token_type id); "
+                       "its results are invalid", whose, err);
+    return 0;
+}
 
 template <typename T>
 int dev_alloc(ee_handle* h, T** p, size_t count) {
@@ -202,8 +244,13 @@ const char* const kProfNames[] = {
     "compact|compact_rows_kernel",
     "gather_cls|gather_cls_kernel",
     "cls_probe|attention_idx_kernel+gemm_split_kernel<.., 1>+ln_rows_kernel+gather_cls_kernel (CLS rows of an exit layer, before its decision)",
+    // nested roles: each is timed INSIDE the role named in brackets (so a sum over roles must leave them out)
+    "pair_index|pair_index_kernel [inside prep]",
+    "patch_split|patch_split_kernel [inside gemm_patch]",
+    "head_out|head_out_kernel [inside exit_head]",
 };
-enum { P_PREP = 0, P_EMBT, P_GPATCH, P_EMBV, P_GQKV, P_ATTN, P_GAO, P_LN, P_GUP, P_GDOWN, P_HEAD, P_DECIDE, P_COMPACT, P_GCLS, P_PROBE, P_COUNT };
+enum { P_PREP = 0, P_EMBT, P_GPATCH, P_EMBV, P_GQKV, P_ATTN, P_GAO, P_LN, P_GUP, P_GDOWN, P_HEAD, P_DECIDE, P_COMPACT, P_GCLS, P_PROBE,
+       P_PAIRIDX, P_PSPLIT, P_HEADOUT, P_COUNT };
 
 struct ProfScope {
     ee_handle* h;
@@ -505,6 +552,7 @@ int ee_destroy(ee_handle* h) {
     for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
     if (h->err_host) (void)hipHostFree(h->err_host);
+    for (auto& es : h->errs) if (es.done) (void)hipEventDestroy(es.done);
     for (auto& hs : h->hist) {
         if (hs.counts) (void)hipHostFree(hs.counts);
         if (hs.done) (void)hipEventDestroy(hs.done);
@@ -697,14 +745,18 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
 
     if (!h->fwd_done) HIP_OK(h, hipEventCreateWithFlags(&h->fwd_done, hipEventDisableTiming));
     if (!h->err_host) {
-        HIP_OK(h, hipHostMalloc((void**)&h->err_host, 64, hipHostMallocDefault));
-        *h->err_host = 0;
+        HIP_OK(h, hipHostMalloc((void**)&h->err_host, sizeof(int) * ee_handle::kErrSlots, hipHostMallocDefault));
+        memset(h->err_host, 0, sizeof(int) * ee_handle::kErrSlots);
+        for (auto& es : h->errs) HIP_OK(h, hipEventCreateWithFlags(&es.done, hipEventDisableTiming));
     }
-    if (h->has_fwd && hipEventQuery(h->fwd_done) == hipSuccess && *h->err_host) {
-        const int e = *h->err_host;
-        *h->err_host = 0;
-        return fail(h, "ee_forward: the PREVIOUS forward on this handle reported error flags %d (%s); its results are invalid", e,
-                    (e & mmee::kErrSplitOverflow) ? "split-precision overflow: run this checkpoint with precision \"fp32\"" : "input out of range");
+    {   // errors of earlier forwards: every finished one is looked at now; the slot this forward will use is waited for if need be
+        int e = take_errors(h, false, false);
+        ee_handle::ErrSlot& mine = h->errs[h->err_seq % ee_handle::kErrSlots];
+        if (!e && mine.pending) {
+            (void)hipEventSynchronize(mine.done);
+            e = take_errors(h, false, false);
+        }
+        if (e) return report_errors(h, e, "a PREVIOUS forward on this handle");
     }
     if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
     // the most recent thresholded forward that has finished: its stage populations predict this one's (steady streams repeat)
@@ -726,8 +778,15 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (h->prof_on) { h->prof_recs.clear(); h->prof_used = 0; }
     // split precision attention: attention_idx.hip (pair index built once per forward; default) or, with MMEE_ATTN_V=2 or bucket tables
     // beyond 64 bins, attention_pair.hip (clamped Delta tables gathered per layer and head)
-    static const int attn_v = [] { const char* e = getenv("MMEE_ATTN_V"); return e ? atoi(e) : 0; }();
+    static const int attn_v = mmee::diag_env_int("MMEE_ATTN_V", 0);      // diagnostic library only: 2 forces attention_pair.hip (A/B)
     const bool use_idx = h->split && attn_v == 0 && c.rel_pos_bins <= 64 && c.rel_2d_pos_bins <= 64;
+    if (h->split && !use_idx) {          // attention_pair.hip holds Delta tables up to fixed distances: refuse what it cannot hold
+        AttnArgs chk{};
+        chk.ctx_split = 1; chk.c1 = h->c1; chk.c2 = h->c2;
+        if (!mmee::attention_pair_supports(chk, c.max_rel_pos, c.max_rel_2d_pos))
+            return fail(h, "ee_forward: the split-precision attention kernels cannot hold this relative-position configuration "
+                           "(bins %d / %d, distances %d / %d); use MMEE_PREC_F32", c.rel_pos_bins, c.rel_2d_pos_bins, c.max_rel_pos, c.max_rel_2d_pos);
+    }
     bool need[3] = {false, false, false};
     for (int i = 0; i < c.n_embedding_exits; ++i) need[c.embedding_exits[i]] = true;
 
@@ -741,7 +800,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         pg.K = c.num_channels * c.patch_size * c.patch_size; pg.scale = 1.f;
         pg.tile_counter = next_head(); pg.prio_mode = 1; pg.err_flag = h->err_flag;
         if (h->split && h->patch_s) {
-            mmee::launch_patch_split(pixel_values, h->H1, B, c.num_channels, c.input_size, c.patch_size, mmee::kSplitScaleX, cus, s, h->err_flag);
+            { ProfScope pp(h, P_PSPLIT, s); mmee::launch_patch_split(pixel_values, h->H1, B, c.num_channels, c.input_size, c.patch_size, mmee::kSplitScaleX, cus, s, h->err_flag); }
             pg.A = h->H1; pg.lda = pg.K; pg.W = h->patch_s; pg.alpha = h->patch_inv / mmee::kSplitScaleX;
             launch_gemm_split(pg, EPI_BIAS, B * NP, cus, s);
             return;
@@ -773,9 +832,11 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     {
         ProfScope ps(h, P_PREP, s);
         launch_prep(pa, s);
-        if (h->pair_idx && use_idx)      // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
+        if (h->pair_idx && use_idx) {    // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
+            ProfScope pi(h, P_PAIRIDX, s);
             mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->lut2_dev, h->c2, c.rel_pos_bins,
                                     h->pair_idx, h->idx_stride, s);
+        }
     }
 
     // ---- embeddings --------------------------------------------------------------------------------------------
@@ -850,7 +911,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         HeadOutArgs ho{};
         ho.in = hin; ho.ld = hld; ho.gather = hg; ho.W = hw.out_w; ho.b = hw.out_b; ho.H = H; ho.Ko = hw.out_dim;
         ho.n_docs_ptr = n_docs_ptr; ho.out = out;
-        launch_head_out(ho, B, s);
+        { ProfScope po(h, P_HEADOUT, s); launch_head_out(ho, B, s); }
     };
 
     auto run_exit = [&](const HeadW* hw, const float* in, int ld, const int* gather, bool is_final) {
@@ -1001,7 +1062,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             const bool exit_here = next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1;
             // the mean-pooled final classifier reads every row of the last layer: only exit layers before it can be probed
             bool probe = probe_on && sp && !no_exit && exit_here && l != L - 1;
-            if (probe && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = probe_pays();
+            if (probe && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays();
             beit_qkv();
             if (probe) {
                 beit_probe();
@@ -1104,7 +1165,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // probe first: this layer ends in a decision (an exit head, or the final classifier), split attention kernels, no dump of
         // every layer (the dump keeps every document to the end, so nothing would be saved)
         bool probe = probe_on && sp && !no_exit && (exit_here != last);
-        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = probe_pays();
+        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays();
         layer_qkv();
         if (probe) {
             layer_probe();
@@ -1153,7 +1214,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
     h->last_gate_heads = out_head_logits || out_head_crit;
-    HIP_OK(h, hipMemcpyAsync(h->err_host, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    {
+        const int k = (int)(h->err_seq % ee_handle::kErrSlots);
+        HIP_OK(h, hipMemcpyAsync(h->err_host + k, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_OK(h, hipEventRecord(h->errs[k].done, s));
+        h->errs[k].pending = true;
+        ++h->err_seq;
+    }
     {
         ee_handle::HistSlot& hs = h->hist[h->fwd_seq & 3];
         hs.used = false;
@@ -1178,21 +1245,19 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
     HIP_OK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     std::vector<StageCounts> sc(h->last_stages);
     HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * h->last_stages, hipMemcpyDeviceToHost));
-    int err = 0;
-    HIP_OK(h, hipMemcpy(&err, h->err_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (h->err_host) *h->err_host = 0;          // reported here
+    const int err = take_errors(h, true, true);       // every forward enqueued so far has finished: all of their flags are reported here
     if (n_stages_out) *n_stages_out = h->last_stages;
     for (int i = 0; i < h->last_stages && i < cap; ++i) {
         if (docs_out) docs_out[i] = sc[h->exit_stage[i]].n_docs;
         if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
     }
-    if (err & 32)
-        return fail(h, "ee_forward: internal error (flags %d): the attention kernel found its dynamic LDS region away from address 0", err);
-    if (err & mmee::kErrSplitOverflow)
-        return fail(h, "ee_forward: split-precision overflow (flags %d): an activation left the range of the split-f16 planes (|LayerNorm out|, "
-                       "|Q/sqrt(d)|, |K|, |V|, |GELU out|, |pixel_values| <= 3750, |attention context| <= 937) and was clamped, so the result is WRONG; "
-                       "run this checkpoint with precision \"fp32\"", err);
-    if (err) return fail(h, "ee_forward: input out of range (flags %d: 1 = token id, 2 = bbox outside [0, max_2d), 4 = position id, 8 = token_type id)", err);
+    return report_errors(h, err, "a forward since the last check");
+}
+
+int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask) {
+    if (!h) return 1;
+    h->mask_on = enabled != 0;
+    h->probe_mask = mask;
     return 0;
 }
 
@@ -1360,6 +1425,9 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
     static int* dbg_head = nullptr;
     if (!dbg_head && hipMalloc((void**)&dbg_head, 512) != hipSuccess) return fail(nullptr, "ee_debug_gemm: hipMalloc failed");
     if (hipMemsetAsync(dbg_head, 0, 512, reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return fail(nullptr, "ee_debug_gemm: memset failed");
+#ifndef MMEE_DIAG
+    if (epi & (32 | 512 | 1024)) return fail(nullptr, "ee_debug_gemm: timing variants (wrong results) exist in the diagnostic library only (make diag)");
+#endif
     g.tile_counter = (epi & 16) ? nullptr : dbg_head;    // epi | 16 = static grid stride (A/B switch)
     g.dbg_noload = ((epi & 32) ? 1 : 0) | ((epi & 512) ? 2 : 0) | ((epi & 1024) ? 4 : 0) | (((epi >> 12) & 255) << 8);   // epi bits 12..19: stagger (x 8128 cycles) for odd wave slots   // epi | 512 = no k-loop barrier (DMA variant; timing diagnostic, wrong results)
     g.prio_mode = (epi >> 6) & 3;                         // epi | 64 / 128: static priority variants
@@ -1393,6 +1461,9 @@ int ee_debug_gemm_split(const float* A, const float* W, const float* bias, const
                         const int32_t* row_src, int32_t rows_A, int32_t iters, float* ms_out, void* stream) {
     const int dbg = epi >> 4;            // diagnostic bits (timing only): 16 no in-loop DMA, 32 no barrier, 64 no DMA wait, 128 no epilogue
     epi &= 15;
+#ifndef MMEE_DIAG
+    if (dbg) return fail(nullptr, "ee_debug_gemm_split: timing variants (wrong results) exist in the diagnostic library only (make diag)");
+#endif
     if (!A || !W || !Cout || M < 1 || rows_A < 1 || !mmee::gemm_split_supports(N, K) || epi < 0 || epi > 3 || iters < 1)
         return fail(nullptr, "ee_debug_gemm_split: bad argument (N %% 256, K %% 16)");
     if (epi == EPI_RESID && !resid) return fail(nullptr, "ee_debug_gemm_split: residual epilogue without a residual");

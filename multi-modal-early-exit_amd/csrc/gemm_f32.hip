@@ -578,7 +578,7 @@ void launch_gemm_f32(const GemmArgs& a, int epi, int amode, int max_m, int num_c
     int grid = (g_gemm_wgs_per_cu > 0 ? g_gemm_wgs_per_cu : GEMM_WGS) * num_cus;
     if (tiles < grid) grid = tiles;
     if (grid < 1) grid = 1;
-    static const int env_dma = [] { const char* e = getenv("MMEE_GEMM_DMA"); return e ? atoi(e) : 1; }();   // MMEE_GEMM_DMA=0: register-staged kernel (A/B switch)
+    static const int env_dma = diag_env_int("MMEE_GEMM_DMA", 1);   // diagnostic library only: MMEE_GEMM_DMA=0 = register-staged kernel (A/B switch)
     if (a.use_dma == 1 || (a.use_dma == 0 && env_dma)) {
         if (amode == AMODE_IM2COL) { launch_one_dma<EPI_BIAS, AMODE_IM2COL>(a, grid, s); return; }
         switch (epi) {

@@ -59,6 +59,11 @@ struct SplitCfg {
     static_assert(PA * PROWS * NW == BM && PW * PROWS * NW == BN && PA >= 1 && PW >= 1, "DMA pieces must tile the stage");
     static_assert(EPI_BYTES <= LOOP_BYTES, "epilogue staging must fit in the stage ring");
     static_assert(NST == 2 || NST == 3, "ring depth");
+    // refused at compile time rather than at launch: a configuration the CU cannot hold (round 2's 128 x 64 sub-tile experiment died with
+    // SIGABRT inside ee_debug_gemm_split's GELU / split-output case and left no diagnostic)
+    static_assert(THREADS <= 1024, "a workgroup is at most 16 waves");
+    static_assert(WGS * (LOOP_BYTES + 16) <= 160 * 1024, "LDS budget of a CU (160 KiB) for WGS workgroups");
+    static_assert(WGS * NW <= 32, "wave slots of a CU");
 };
 using CfgA = SplitCfg<128, 256, 64, 3, 2, 4, 2>;
 using CfgB = SplitCfg<256, 256, 128, 2, 4, 4, 1>;
@@ -509,32 +514,14 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
     hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
 }
 
-// CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283);
-// MMEE_SPLIT_CFG=A / B force the other configurations (A/B measurements).
+// CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283), CfgP for the CLS-probe
+// GEMMs.  The release library holds exactly these; the other configurations (MMEE_SPLIT_CFG=1 / 2 for CfgA / CfgB) and the timing
+// diagnostics (GemmArgs::dbg_noload, wrong results) are compiled into the diagnostic library only (make diag, -DMMEE_DIAG).
 void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
-    static const int forced = [] { const char* e = getenv("MMEE_SPLIT_CFG"); return e ? (e[0] == 'A' ? 1 : e[0] == 'B' ? 2 : e[0] == 'C' ? 3 : 0) : 0; }();
-    if (a.probe && !a.dbg_noload && (forced == 3 || forced == 0)) {      // CLS probe: the default configuration under its own kernel name
-        if (a.out_split && epi == EPI_GELU) launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s);
-        else if (!a.out_split && epi == EPI_RESID) launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s);
-        else abort();                    // the probe launches no other shape
-        return;
-    }
-    if ((forced == 3 || forced == 0) && !a.dbg_noload) {      // default: CfgC
-        if (a.out_split) {
-            if (epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true>(a, max_m, num_cus, s);
-            else launch_split_one<CfgC, EPI_BIAS, true>(a, max_m, num_cus, s);
-            return;
-        }
-        switch (epi) {
-            case EPI_BIAS: launch_split_one<CfgC, EPI_BIAS, false>(a, max_m, num_cus, s); break;
-            case EPI_GELU: launch_split_one<CfgC, EPI_GELU, false>(a, max_m, num_cus, s); break;
-            case EPI_RESID: launch_split_one<CfgC, EPI_RESID, false>(a, max_m, num_cus, s); break;
-            default: launch_split_one<CfgC, EPI_TANH, false>(a, max_m, num_cus, s); break;
-        }
-        return;
-    }
+#ifdef MMEE_DIAG
+    static const int forced = diag_env_int("MMEE_SPLIT_CFG", 0);      // 1 = CfgA, 2 = CfgB, 0 / 3 = CfgC
     const bool use_a = forced == 1;
-    if (a.dbg_noload && forced == 0) {      // timing diagnostics of the default configuration (tools/gemm_split_shapes.py)
+    if (a.dbg_noload && (forced == 0 || forced == 3)) {      // timing diagnostics of the default configuration (tools/gemm_split_shapes.py)
         if (a.out_split && epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true, true>(a, max_m, num_cus, s);
         else if (a.out_split) launch_split_one<CfgC, EPI_BIAS, true, true>(a, max_m, num_cus, s);
         else launch_split_one<CfgC, EPI_RESID, false, true>(a, max_m, num_cus, s);
@@ -546,27 +533,47 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
         else launch_split_one<CfgB, EPI_RESID, false, true>(a, max_m, num_cus, s);
         return;
     }
-    if (a.out_split) {
-        if (epi == EPI_GELU && use_a) launch_split_one<CfgA, EPI_GELU, true>(a, max_m, num_cus, s);
-        else if (epi == EPI_GELU) launch_split_one<CfgB, EPI_GELU, true>(a, max_m, num_cus, s);
-        else if (use_a) launch_split_one<CfgA, EPI_BIAS, true>(a, max_m, num_cus, s);
-        else launch_split_one<CfgB, EPI_BIAS, true>(a, max_m, num_cus, s);      // QKV projection -> split Q | K | V rows
-        return;
-    }
-    if (use_a) {
+    if (forced == 1 || forced == 2) {
+        if (a.out_split) {
+            if (epi == EPI_GELU && use_a) launch_split_one<CfgA, EPI_GELU, true>(a, max_m, num_cus, s);
+            else if (epi == EPI_GELU) launch_split_one<CfgB, EPI_GELU, true>(a, max_m, num_cus, s);
+            else if (use_a) launch_split_one<CfgA, EPI_BIAS, true>(a, max_m, num_cus, s);
+            else launch_split_one<CfgB, EPI_BIAS, true>(a, max_m, num_cus, s);
+            return;
+        }
+        if (use_a) {
+            switch (epi) {
+                case EPI_BIAS: launch_split_one<CfgA, EPI_BIAS, false>(a, max_m, num_cus, s); break;
+                case EPI_GELU: launch_split_one<CfgA, EPI_GELU, false>(a, max_m, num_cus, s); break;
+                case EPI_RESID: launch_split_one<CfgA, EPI_RESID, false>(a, max_m, num_cus, s); break;
+                default: launch_split_one<CfgA, EPI_TANH, false>(a, max_m, num_cus, s); break;
+            }
+            return;
+        }
         switch (epi) {
-            case EPI_BIAS: launch_split_one<CfgA, EPI_BIAS, false>(a, max_m, num_cus, s); break;
-            case EPI_GELU: launch_split_one<CfgA, EPI_GELU, false>(a, max_m, num_cus, s); break;
-            case EPI_RESID: launch_split_one<CfgA, EPI_RESID, false>(a, max_m, num_cus, s); break;
-            default: launch_split_one<CfgA, EPI_TANH, false>(a, max_m, num_cus, s); break;
+            case EPI_BIAS: launch_split_one<CfgB, EPI_BIAS, false>(a, max_m, num_cus, s); break;
+            case EPI_GELU: launch_split_one<CfgB, EPI_GELU, false>(a, max_m, num_cus, s); break;
+            case EPI_RESID: launch_split_one<CfgB, EPI_RESID, false>(a, max_m, num_cus, s); break;
+            default: launch_split_one<CfgB, EPI_TANH, false>(a, max_m, num_cus, s); break;
         }
         return;
     }
+#endif
+    if (a.probe) {      // CLS probe: 128 x 128 tiles under their own kernel name; same MFMA form, k order and term order as CfgC => the same bits
+        if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
+        // not a shape the probe launches: the default configuration below computes the same bits
+    }
+    if (a.out_split) {
+        if (epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true>(a, max_m, num_cus, s);
+        else launch_split_one<CfgC, EPI_BIAS, true>(a, max_m, num_cus, s);
+        return;
+    }
     switch (epi) {
-        case EPI_BIAS: launch_split_one<CfgB, EPI_BIAS, false>(a, max_m, num_cus, s); break;
-        case EPI_GELU: launch_split_one<CfgB, EPI_GELU, false>(a, max_m, num_cus, s); break;
-        case EPI_RESID: launch_split_one<CfgB, EPI_RESID, false>(a, max_m, num_cus, s); break;
-        default: launch_split_one<CfgB, EPI_TANH, false>(a, max_m, num_cus, s); break;
+        case EPI_BIAS: launch_split_one<CfgC, EPI_BIAS, false>(a, max_m, num_cus, s); break;
+        case EPI_GELU: launch_split_one<CfgC, EPI_GELU, false>(a, max_m, num_cus, s); break;
+        case EPI_RESID: launch_split_one<CfgC, EPI_RESID, false>(a, max_m, num_cus, s); break;
+        default: launch_split_one<CfgC, EPI_TANH, false>(a, max_m, num_cus, s); break;
     }
 }
 

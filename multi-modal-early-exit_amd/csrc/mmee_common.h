@@ -3,7 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace mmee {
+
+// A/B and diagnostic switches exist only in the DIAGNOSTIC library (`make diag` -> libmmee_hip_diag.so, built with -DMMEE_DIAG, loaded by
+// tools/ through MMEE_LIB): the release library never reads the environment, so no variable can change what it computes.
+inline int diag_env_int(const char* name, int dflt) {
+#ifdef MMEE_DIAG
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

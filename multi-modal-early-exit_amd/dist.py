@@ -77,7 +77,7 @@ def broadcast_array(a: np.ndarray, src: int = 0, device=None, group=None) -> np.
     """Every rank gets rank ``src``'s array (thresholds / temperatures are inputs of the path, EE/policy.py:12-24: every
     shard must test its documents against the same values)."""
     import torch.distributed as dist
-    t = torch.from_numpy(np.ascontiguousarray(a))
+    t = torch.from_numpy(np.array(a, copy=True, order="C"))      # a copy: the collective writes into its buffer, the caller's array stays
     if dist.get_backend(group) == "nccl":
         t = t.to(device)
     dist.broadcast(t, src, group=group)

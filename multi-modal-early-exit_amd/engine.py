@@ -287,6 +287,22 @@ class EarlyExitEngine:
         return {"gemm": g.value, "attention": a.value, "probe": plan["probe_flops"],
                 "total": g.value + a.value + plan["probe_flops"]}
 
+    def pin_schedule(self, probe_layers=None):
+        """Pin which exit layers are probed first (ee_set_probe_mask).  ``probe_layers``: iterable of 0-based layer indices; ``None``
+        pins the plan the LAST forward ran (synchronises); ``False`` returns to the default (chosen per layer from the stage
+        populations of the most recent finished forward, which makes the launch sequence depend on timing).  Returns the list."""
+        if probe_layers is False:
+            capi.check(self.lib.ee_set_probe_mask(self._h, 0, 0), self._h, "ee_set_probe_mask")
+            return None
+        if probe_layers is None:
+            probe_layers = [l for l, d in enumerate(self.layer_plan()["docs_probe"]) if d > 0]
+        layers = sorted(int(l) for l in probe_layers)
+        mask = 0
+        for l in layers:
+            mask |= 1 << l
+        capi.check(self.lib.ee_set_probe_mask(self._h, 1, mask), self._h, "ee_set_probe_mask")
+        return layers
+
     def layer_plan(self):
         """How the last forward ran each encoder layer (ee_last_layer_plan): rows through Q|K|V, rows through the rest of
         the layer, documents whose CLS row was probed before the layer's decision."""

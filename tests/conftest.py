@@ -40,3 +40,23 @@ TINY_CASES = {
 BASE_EE = dict(exits=["text_visual_concat", 2, 4, 6, 8, 10], encoder_layer_strategy="ramp")
 DIT_EE = dict(exits=[1, 2, 3, 4], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
 DIT_BASE_EE = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+
+# criterion / head / strategy matrix at the two shapes the split-precision kernels care about (tests/golden/make_golden.py "matrix"):
+# name -> (shape, EE_config, n_docs, text_len).  "h256" = the smallest shape the split kernels accept; "base" = LayoutLMv3-base, S = 709.
+H256_KW = dict(hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3, coordinate_size=48, shape_size=32)
+MATRIX_CASES = {
+    "h256_entropy_1layer": ("h256", dict(exits=["vision_avg", "text_avg", "text_visual_concat", 1, 2, 3], encoder_layer_strategy="ramp",
+                                          inference_strategy="entropy", exit_head_num_layers=1), 6, 48),
+    "h256_gate": ("h256", dict(exits=["text_avg", 1, 2], encoder_layer_strategy="gate", inference_strategy="max_confidence"), 6, 48),
+    "base_emb_entropy_1layer": ("base", dict(exits=["vision_avg", "text_avg", 6], encoder_layer_strategy="ramp",
+                                             inference_strategy="entropy", exit_head_num_layers=1), 2, 512),
+    "base_gate": ("base", dict(exits=["vision_avg", "text_visual_concat", 6], encoder_layer_strategy="gate",
+                               inference_strategy="max_confidence"), 2, 512),
+}
+MATRIX_SEEDS = dict(seed_w=31, seed_docs=32)
+
+
+def matrix_config(pkg, name):
+    shape, ee, n_docs, T = MATRIX_CASES[name]
+    cfg = pkg.ModelConfig.base(EE_config=ee) if shape == "base" else pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
+    return cfg, ee, n_docs, T

@@ -283,8 +283,31 @@ def make_dit_golden():
     print("dit golden done", res["logits"][0, :4])
 
 
+def make_matrix_golden():
+    """Criterion / head-depth / strategy matrix at the smallest split-precision shape (H = 256) and at base shape: entropy criterion,
+    one-layer heads, gates, vision_avg / text_avg exits (EE/models/EE_modules.py:116-160, EE/models/LayoutLMv3.py:70-93, 465-605,
+    764-792).  Same composed reference as main(); case table in tests/conftest.py (MATRIX_CASES)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import MATRIX_CASES, MATRIX_SEEDS, matrix_config
+    for name in MATRIX_CASES:
+        cfg, ee, n_docs, T = matrix_config(pkg, name)
+        W = pkg.synth.make_weights(cfg, seed=MATRIX_SEEDS["seed_w"])
+        docs = pkg.synth.make_documents(cfg, n_docs, seed=MATRIX_SEEDS["seed_docs"], text_len=T, min_words=3)
+        res = run_reference(cfg, W, docs, ee)
+        conf = np.exp(res["logits_store"] - res["logits_store"].max(-1, keepdims=True))
+        conf = np.sort(np.unique(np.round((conf / conf.sum(-1, keepdims=True)).max(-1), 6)))
+        mid = float(conf[len(conf) // 2]) + 1e-4
+        policy_fixture(res["logits_store"], [0.0, mid, 0.9, 1.0 + 1e-6], "pol", res)
+        keep = {k: v for k, v in res.items() if k not in ("emb_out_row1", "emb_out_lastrow", "layer1_row1")}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), n_docs=n_docs, text_len=T, sha_input_ids=sha(docs["input_ids"]),
+                            sha_pixel_values=sha(docs["pixel_values"]), **MATRIX_SEEDS, **keep)
+        print(name, "E =", res["exit_logits"].shape[0], "store[:, 0, :3] =", res["logits_store"][:, 0, :3].ravel()[:6])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
+    if len(sys.argv) > 1 and sys.argv[1] == "matrix":
+        make_matrix_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         make_preprocess_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "dit":
         make_dit_golden()
@@ -292,3 +315,4 @@ if __name__ == "__main__":
         main()
         make_preprocess_golden()
         make_dit_golden()
+        make_matrix_golden()

@@ -133,6 +133,53 @@ def test_input_validation_flags(pkg):
     assert np.isfinite(out.logits.cpu().numpy()).all()
     with pytest.raises(pkg.capi.MMEEError):
         eng.forward(np.zeros((9, 48), np.int64), None, np.zeros((9, 48, 4), np.int64), np.zeros((9, 3, 64, 64), np.float32))
+
+
+def test_error_of_an_earlier_forward_survives_later_forwards(pkg):
+    """ee_forward only enqueues.  A batch with an out-of-range box followed by good batches, nothing synchronised in between: the
+    error of the FIRST forward must still be reported (each forward has its own pinned error word; a later forward used to overwrite it)."""
+    import torch
+    g = load_golden("tiny_ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48)
+    eng.load_weights(pkg.synth.make_weights(cfg, seed=7))
+    good = (g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"])
+    bad_box = g["in_bbox"].copy()
+    bad_box[0, 1, 2] = 5000
+    bad = (g["in_input_ids"], g["in_attention_mask"], bad_box, g["in_pixel_values"])
+    def drain(seq):
+        """enqueue the batches, then check(): every error raised on the way (a forward that reports an earlier error does not run)"""
+        errs = []
+        for batch in seq:
+            try:
+                eng.forward(*batch)
+            except pkg.capi.MMEEError as e:
+                errs.append(str(e))
+        try:
+            eng.check()
+        except pkg.capi.MMEEError as e:
+            errs.append(str(e))
+        return errs
+
+    # bad, good, good with nothing synchronised in between: exactly one report, whichever call gets to make it
+    errs = drain([bad, good, good])
+    assert len(errs) == 1 and "out of range" in errs[0], errs
+    assert drain([good]) == []                    # reported once: the handle is clean again
+    # the device drains before anybody looks: the NEXT forward refuses to run
+    eng.forward(*bad)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.capi.MMEEError, match="PREVIOUS forward"):
+        eng.forward(*good)
+    out = eng.forward(*good, validate=True)       # and works afterwards
+    assert np.isfinite(out.logits.cpu().numpy()).all()
+    # more forwards in flight than the ring has slots (8): the slot of the bad one is waited for before it is reused
+    errs = drain([bad] + [good] * 12)
+    assert len(errs) == 1 and "out of range" in errs[0], errs
+    # two bad batches: one report each, unless the second was refused because the first had just been reported
+    errs = drain([bad, good, bad, good, good])
+    assert 1 <= len(errs) <= 2 and all("out of range" in e for e in errs), errs
+    assert drain([good, good]) == []
+    eng.close()
     W = pkg.synth.make_weights(cfg, seed=7)
     W.pop("classifier.dense.weight")
     with pytest.raises(KeyError):
@@ -352,6 +399,19 @@ def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
         assert abs(metrics["ece"][e] - pkg.calibration.expected_calibration_error(labels, val[e] / T[e])) < 1e-12
         assert metrics["ece"][e] < pkg.calibration.expected_calibration_error(labels, val[e]) + 1e-3    # scaling does not hurt calibration
         assert abs(metrics["accuracy"][e] - np.mean(val[e].argmax(-1) == labels)) < 1e-12
+    # metrics_on="reference": the numbers EE/eval.py:321-337 records (scaled TEST logits scored against the validation references)
+    cal_r, m_r = pkg.calibration.calibrate(val, labels, test, metrics_on="reference")
+    np.testing.assert_array_equal(cal_r, cal)
+    assert m_r["temperature"] == metrics["temperature"]
+    for e in range(E1):
+        z = test[e] / T[e]
+        sm = oracle.softmax64(z)
+        assert abs(m_r["accuracy"][e] - np.mean(z.argmax(-1) == labels)) < 1e-12
+        assert abs(m_r["average_confidence"][e] - sm.max(-1).mean()) < 1e-12
+        assert abs(m_r["ece"][e] - pkg.calibration.expected_calibration_error(labels, z)) < 1e-12
+    assert m_r["accuracy"] != metrics["accuracy"]            # `test` is the validation set reversed: its argmax no longer matches the labels
+    with pytest.raises(ValueError):
+        pkg.calibration.calibrate(val, labels, test[:, :-1], metrics_on="reference")
     cfgp = {"exit_threshold": 0.5, "device": "cpu", "epsilon": 0.05, "calibration_metrics": metrics}
     ex, pred, dist = pkg.Policy(cal, cfgp).accuracy_calibration_heuristic()
     thr = oracle.heuristic_thresholds(metrics["accuracy"], metrics["ece"], 0.05)

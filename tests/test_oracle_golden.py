@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from .conftest import BASE_EE, TINY_CASES, load_golden
+from .conftest import BASE_EE, MATRIX_CASES, MATRIX_SEEDS, TINY_CASES, load_golden, matrix_config
 
 
 def test_bucket_lut_matches_hf(oracle):
@@ -33,6 +33,28 @@ def test_tiny_forward_matches_reference(pkg, oracle, name):
     np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
     if "gated_logits" in g:
         np.testing.assert_allclose(out["gated_logits"], g["gated_logits"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", [n for n in MATRIX_CASES if n.startswith("h256")])
+def test_matrix_h256_forward_matches_reference(pkg, oracle, name):
+    """Entropy criterion, one-layer heads, gate strategy, every embedding-level exit at H = 256 (the smallest split-precision shape)."""
+    g = load_golden(name)
+    cfg, ee, n_docs, T = matrix_config(pkg, name)
+    W = pkg.synth.make_weights(cfg, seed=MATRIX_SEEDS["seed_w"])
+    docs = pkg.synth.make_documents(cfg, n_docs, seed=MATRIX_SEEDS["seed_docs"], text_len=T, min_words=3)
+    ec = cfg.exit_config
+    out = oracle.forward_all(cfg, W, docs, ec.exits, strategy=str(ec.encoder_layer_strategy), criterion=str(ec.inference_strategy),
+                             return_hidden_cls=True)
+    scale = max(1.0, float(np.abs(g["logits_store"]).max()))
+    np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["exit_logits"], g["exit_logits"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["exit_crit"], g["exit_crit"], rtol=0, atol=2e-5 * scale)
+    if "gated_logits" in g:
+        np.testing.assert_allclose(out["gated_logits"], g["gated_logits"], rtol=0, atol=1e-4)
+    for i in range(4):
+        ex, pred, _ = oracle.policy_scan(g["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex, g[f"pol_exits{i}"])
 
 
 def test_tiny_policy_matches_reference(oracle):

@@ -1,5 +1,8 @@
 """Phase shares of the head-pair attention kernel (diagnostic build with in-kernel stamps): run as
 `MMEE_ATTN_STAMPS=1 python tools/attn_stamps.py` on the GPU box.  Shares, not times (the stamps fence the phases apart)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

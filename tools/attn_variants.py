@@ -1,5 +1,8 @@
 """Timing variants of the head-pair attention kernel (MMEE_ATTN_DBG bits: 1 no bias gathers, 2 no softmax VALU, 4 no LDS-DMA,
 8 no P V) — wrong results, timing only.  Prints attention ms per forward from ee_profile for the variant in the environment."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,4 +23,5 @@ eng.forward(*args, dump_all=True)
 p = eng.profile_read()
 fl = eng.flops()
 ms = p["attention"]["ms"]
-print(f"dbg={os.environ.get('MMEE_ATTN_DBG', '0')} v={os.environ.get('MMEE_ATTN_V', 'pair')} attention {ms:.2f} ms / forward  ({fl['attention'] / ms / 1e9:.1f} TFLOP/s algorithmic)")
+sw = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MMEE_ATTN_"))
+print(f"[{sw}] attention {ms:.2f} ms / forward  ({fl['attention'] / ms / 1e9:.1f} TFLOP/s algorithmic)  B={B}")

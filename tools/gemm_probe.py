@@ -1,4 +1,7 @@
 """Micro-benchmark of the path's GEMM kernel through ee_debug_gemm (GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import ctypes as C
 import importlib
 import os

@@ -1,4 +1,7 @@
 """A few launches of the split GEMM at the FFN shapes, for rocprofv3 --pmc passes (GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gemm_split_probe import run

@@ -1,4 +1,7 @@
 """FFN-down shaped split GEMM at tile counts around a multiple of the 256 CUs: what the last, partly filled round costs (GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gemm_split_probe import run

@@ -1,4 +1,7 @@
 """In-kernel stamp shares of the GEMM main loop (diagnostic build; read SHARES, not run time)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _diag  # noqa: F401  (diagnostic library)
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
