@@ -22,6 +22,7 @@
 //     rescaling (reference maximum moved only when exceeded by 2^5), K / V tiles by LDS-DMA into a double-buffered ring with ONE
 //     barrier per 32 keys, the next tile's DMA issued between the MFMAs, 3 workgroups of 4 waves per CU.
 #include <cstdlib>
+#include <type_traits>
 #include "mmee_common.h"
 
 namespace mmee {
@@ -32,15 +33,20 @@ constexpr int KT = 32;         // keys per tile
 constexpr int D = 64;          // head dim
 constexpr int TILE_BYTES = KT * 256;          // K (or V) tile: 32 rows x (64 hi + 64 lo) f16
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;   // K | V
+constexpr int RING = 3;                       // ring depth of the K / V stages
 constexpr int BINS_MAX = 64;
-// LDS layout: bucket tables, queue slot, K / V ring
-constexpr int OFF_T1 = 0;                     // (bins1 + 1) floats (last = masked-key sentinel)
-constexpr int OFF_TX = 272;
-constexpr int OFF_TY = 528;
-constexpr int OFF_QSLOT = 784;
-constexpr int OFF_STAGE = 1024;
+// LDS layout: the K / V ring FIRST (slot s at s * 16 KiB: every tile base is a multiple of 8 KiB, so a lane's offset inside a tile and the
+// tile base never share a bit and "base + (offset ^ c)" is "(base + offset) ^ c": one add per tile, one XOR per read), then the bucket
+// tables and the queue slot
+constexpr int OFF_TAB = RING * STAGE_BYTES;   // 49152
+constexpr int OFF_T1 = OFF_TAB;               // (bins1 + 1) floats (last = masked-key sentinel)
+constexpr int OFF_TX = OFF_TAB + 272;
+constexpr int OFF_TY = OFF_TAB + 528;
+constexpr int OFF_QSLOT = OFF_TAB + 784;
+constexpr int LDS_BYTES = OFF_TAB + 1024;
 constexpr int WGS = 3;
 static_assert(OFF_T1 + 4 * (BINS_MAX + 1) <= OFF_TX && OFF_TX + 4 * BINS_MAX <= OFF_TY && OFF_TY + 4 * BINS_MAX <= OFF_QSLOT, "tables");
+static_assert(WGS * LDS_BYTES <= 160 * 1024 && OFF_TY + 4 * BINS_MAX < 65536, "LDS budget / 16-bit instruction offsets");
 constexpr float kNegBig = -1.0e30f;
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kPShift = 10.0f;              // probabilities carry 2^10 into the split planes
@@ -123,15 +129,29 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads; its run time means
-// nothing, the SHARES do); 2 timing variants selected by `dbg` (wrong results).  Modes 1 and 2 are never in the path.
-// RING = ring depth of the K / V stages.  2: the next tile's DMA is issued during a tile and waited for (vmcnt(0)) at the top of the next; the
-// pair-index words are plain loads issued at the end of the previous tile.  3: the DMA of tile kt + 2 is issued during tile kt, every wait is
-// COUNTED (a tile never waits for a DMA it does not need yet), and the index words are asm loads issued right behind the barrier and consumed
-// after the Q K^T MFMAs of the same tile (the bias is then added to the finished scores instead of initialising the accumulator): no
-// compiler-visible vector load is in flight beside the DMA, whose completion hipcc would otherwise wait for at the load's first use.
-template <int MODE, int RING, bool PF, int WPS = WGS>
-__global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
+// The attention kernel.  MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads;
+// its run time means nothing, the SHARES do); 2 timing variants selected by `dbg` (wrong results).  Modes 1 and 2 exist in the
+// diagnostic library only (-DMMEE_DIAG).  BIAS: relative-position bias from the pair index (LayoutLMv3) or none (image-only).
+//
+// Round-3 timing variants (tools/attn_ab.sh) showed what binds this kernel: removing all 12 Q K^T MFMAs of a tile saves 3 %, removing
+// the barrier nothing, while every other piece costs about what its INSTRUCTIONS cost to issue (index loads 16 %, K / V DMA issue 16 %,
+// softmax 12 %, P V incl. its fragment reads and conversions 19 %) -- the matrix pipe is hidden, the waves are bound by the vector /
+// scalar / LDS instructions they have to issue.  Hence the shape of the loop below:
+//   * FOUR compile-time variants of a key tile (HOT: the tile two ahead is a full tile; TAIL: it is the document's partial last tile;
+//     PENULT / LAST: nothing left to fetch), picked by the loop structure, so that a tile's body has no branch, no clamp and a constant
+//     wait count; the old body spent ~150 scalar instructions and ~30 branches per tile on "is there a next tile, is it whole";
+//   * one scalar tile pointer advanced per tile; a piece's row offset rides in the lane offset (one v_xad_u32 per piece);
+//   * the ring at LDS 0 (see the layout above): V / K fragment addresses are one XOR each;
+//   * the lo plane of P by v_fma_mixlo / mixhi_f16 (x - f16(x) rounded to f16 in one instruction instead of three);
+//   * the index words of tile kt + 1 are fetched as soon as the lookups of tile kt have consumed the registers (a whole softmax + P V +
+//     barrier + Q K^T ahead of their use); they are read-write asm operands, so input and output are ONE register by construction and
+//     the loop's back edge needs no copy (a copy in front of the wait would read words that have not landed).
+// Waits are hand-counted: from the Q loads to the end of an item only asm vector-memory operations are in flight (hipcc would wait
+// vmcnt(0) at the first use of a compiler-visible load while an LDS-DMA is pending).
+enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
+
+template <int MODE, bool BIAS>
+__global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
     const int n_docs = a.counts->n_docs;
     const int qtiles = (a.max_len + QT - 1) / QT;
     const int n_pairs = n_docs * a.heads;
-    const size_t row_bytes = (size_t)a.ld * 4;         // a split row of Q | K | V occupies the bytes of ld floats
+    const unsigned row_bytes = (unsigned)a.ld * 4u;    // a split row of Q | K | V occupies the bytes of ld floats
     const float sc2 = a.qkv_scale * a.qkv_scale;       // score accumulators carry s_q * s_k
     const float cexp = kLog2e / sc2;                   // exponent = acc * cexp
     const float lazy = kLazyLog2 / cexp;
@@ -149,7 +169,6 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
         if (threadIdx.x == 0 && a.err_flag) atomicOr(a.err_flag, 32);
         return;
     }
-    const bool has_bias = a.pair_idx != nullptr;
 
     int* q_slot = reinterpret_cast<int*>(smem + OFF_QSLOT);
     const int my_xcd = a.item_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
@@ -164,18 +183,19 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
     // lane & 15).  The logical chunk it must fetch is phys ^ swz(row), swz = ((row & 3) << 2) | ((row >> 2) & 3) = (((lane >> 4) & 3) << 2) | (j & 3);
     // logical chunk ch = 8 plane + 2 group + half  <->  global chunk 4 group + 2 plane + half of the head's 256 contiguous bytes.
     // For piece j the global chunk offset is g0 ^ (16 (j & 1) + 64 ((j >> 1) & 1)) with g0 the j = 0 value, and row_bytes is a multiple of
-    // 256, so the lane's whole source offset is ONE register XOR-ed with a constant per piece (nothing to keep live, nothing to spill: a
-    // spilled operand would be reloaded with a vmcnt(0) wait right in front of the DMA issue and serialise the pieces).
+    // 256, so the lane's whole source offset is ONE register XOR-ed with a constant per piece, plus the piece's row offset.
     const unsigned ch0 = (unsigned)(lane & 15) ^ ((((unsigned)lane >> 4) & 3u) << 2);
-    const unsigned vdma0 = ((unsigned)lane >> 4) * (unsigned)row_bytes + 16u * (4u * ((ch0 >> 1) & 3u) + 2u * (ch0 >> 3) + (ch0 & 1u));
+    const unsigned vdma0 = ((unsigned)lane >> 4) * row_bytes + 16u * (4u * ((ch0 >> 1) & 3u) + 2u * (ch0 >> 3) + (ch0 & 1u));
     const int img = wave >> 1, pstart = (wave & 1) * 4;  // waves 0, 1 fill K (pieces 0-3, 4-7), waves 2, 3 fill V
+    const unsigned dst_wave = (unsigned)img * TILE_BYTES + 1024u * (unsigned)pstart;      // this wave's four pieces inside a ring slot
     // transposed-read addressing of V (constant per lane): 16-lane group g = lane >> 4 serves (h = g >> 1, d block 16 (g & 1));
     // lane 4q + p of the group supplies row key0 + q, d = d0 + 4p .. 4p + 3.  With row0 = 4 (g >> 1) + q and dch0 = 2 (g & 1) + (p >> 1):
     // img_off(16 ks + row0 + 8 x, dch0 + 4 dh + 8 plane) + 8 (p & 1) = (vbase ^ (32 x + 64 dh + 128 plane)) + 2048 x + 4096 ks
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
-    const unsigned vbase = img_off(4 * (tg >> 1) + tq, 2 * (tg & 1) + (tp >> 1)) + 8u * (unsigned)(tp & 1);
+    const unsigned vbase = img_off(4 * (tg >> 1) + tq, 2 * (tg & 1) + (tp >> 1)) + 8u * (unsigned)(tp & 1) + (unsigned)TILE_BYTES;      // V image of slot 0
     // K row reads: chunk (2 st + hh) + 8 plane of row l31 = kbase ^ (32 st + 128 plane)
     const unsigned kbase = img_off(l31, hh);
+    const unsigned ivoff = 16u * (unsigned)lane;
 
     for (;; item += gridDim.x) {
         int doc, head, qt;
@@ -220,7 +240,7 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
         if (DIAG) tprev = stamp_now();
 
         __syncthreads();                               // previous item's LDS reads are done
-        if (head != cur_head && has_bias) {            // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
+        if (BIAS && head != cur_head) {                // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
             float* T1 = reinterpret_cast<float*>(smem + OFF_T1);
             float* TX = reinterpret_cast<float*>(smem + OFF_TX);
             float* TY = reinterpret_cast<float*>(smem + OFF_TY);
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
             cur_head = head;
         }
 
-        const int slab = has_bias ? __builtin_amdgcn_readfirstlane(a.doc_orig[doc]) : 0;      // fetched before the counted regime starts
+        const int slab = BIAS ? __builtin_amdgcn_readfirstlane(a.doc_orig[doc]) : 0;      // fetched before the counted regime starts
         const int qb = (q0 >> 5) + wave;               // this wave's 32-query block of the document
         const int qi = q0 + wave * 32 + l31;           // this lane's query (both lane halves hold the same query)
         const bool wave_active = (q0 + wave * 32) < qlen;
@@ -241,61 +261,57 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
         f16x8 qh[4], ql[4];
         {
             const char* qp = reinterpret_cast<const char*>(a.qkv) + (size_t)qrow * row_bytes + (size_t)head * 256 + 16 * hh;
-            if constexpr (RING == 3) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table fill / previous item's stores: done before the counted regime starts
-                // asm loads: from here to the end of the item only hand-counted vector memory operations are in flight.  They are older than
-                // the first tiles' DMA pieces issued below, so the counted wait at the top of tile 0 covers them; no wait of their own.
-                asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
-                             "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
-                             "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
-                             "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224"
-                             : "=&v"(qh[0]), "=&v"(ql[0]), "=&v"(qh[1]), "=&v"(ql[1]), "=&v"(qh[2]), "=&v"(ql[2]), "=&v"(qh[3]), "=&v"(ql[3])
-                             : "v"(qp)
-                             : "memory");
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    qh[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s);
-                    ql[s] = *reinterpret_cast<const f16x8*>(qp + 64 * s + 32);
-                }
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table fill / previous item's stores: done before the counted regime starts
+            // asm loads: from here to the end of the item only hand-counted vector memory operations are in flight.  They are older than
+            // the first tiles' DMA pieces issued below, so the counted wait at the top of tile 0 covers them; no wait of their own.
+            asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
+                         "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
+                         "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
+                         "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224"
+                         : "=&v"(qh[0]), "=&v"(ql[0]), "=&v"(qh[1]), "=&v"(ql[1]), "=&v"(qh[2]), "=&v"(ql[2]), "=&v"(qh[3]), "=&v"(ql[3])
+                         : "v"(qp)
+                         : "memory");
         }
 
-        // ---- LDS-DMA of one key tile: K / V pieces into ring slot `buf`, this wave's pair-index tile into its private buffer ------
+        // ---- LDS-DMA of the K / V tiles.  kv_wave: first row of THIS WAVE's four pieces of tile 0 (K or V section of the head) ----
         const size_t sect = (size_t)(img + 1) * (size_t)a.H * 4 + (size_t)head * 256;
-        const char* kv_base = reinterpret_cast<const char*>(a.qkv) + (size_t)qoff * row_bytes + sect;
-        const unsigned* idx_base = has_bias ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
-        auto issue_kv = [&](int kt, int buf, int jj) __attribute__((always_inline)) {      // piece jj (0..3) of this wave's share
+        const char* kv_doc = reinterpret_cast<const char*>(a.qkv) + (size_t)qoff * row_bytes + sect;
+        const unsigned tile_step = KT * row_bytes, piece_step = 4u * row_bytes;
+        const char* kv_wave = kv_doc + (size_t)(4 * pstart) * row_bytes;
+        // whole tile inside the document: piece jj = rows 4 (pstart + jj) .. + 3; the row offset rides in the lane offset
+        auto issue_full = [&](int kt, unsigned sbase, int jj) __attribute__((always_inline)) {
             if (MODE == 2 && (dbg & 4)) return;
             if (MODE == 2 && (dbg & 16)) kt = 0;       // timing variant: every tile re-fetches the document's first rows (L2-resident source)
-            const int k0 = kt * KT;
-            const int j = pstart + jj;
-            const unsigned dst = (unsigned)OFF_STAGE + (unsigned)buf * STAGE_BYTES + (unsigned)img * TILE_BYTES + 1024u * (unsigned)j;
-            const unsigned cj = 16u * (unsigned)(j & 1) + 64u * (unsigned)((j >> 1) & 1);
+            const unsigned cj = 16u * (unsigned)(jj & 1) + 64u * (unsigned)((jj >> 1) & 1);
             unsigned vd = vdma0;
             asm volatile("" : "+v"(vd));               // opaque: recomputed per piece, never a set of precomputed (spillable) registers
-            if (k0 + KT <= len) {                      // whole tile inside the document: the row goes into the scalar base
-                const unsigned long long base = (unsigned long long)(size_t)(kv_base + (size_t)(k0 + 4 * j) * row_bytes);
-                dma16(vd ^ cj, base, dst);
-            } else {                                   // last tile: rows past the document are clamped to its last row (and masked)
-                const unsigned long long base = (unsigned long long)(size_t)(kv_base + (size_t)k0 * row_bytes);
-                const int lim = len - 1 - k0;
-                const int pr = (int)((unsigned)lane >> 4);
-                int r = 4 * j + pr;
-                r = r < lim ? r : lim;
-                dma16((vd ^ cj) + (unsigned)(r - pr) * (unsigned)row_bytes, base, dst);
-            }
+            const unsigned long long base = (unsigned long long)(size_t)(kv_wave + (size_t)kt * tile_step);
+            dma16((vd ^ cj) + (unsigned)jj * piece_step, base, sbase + dst_wave + 1024u * (unsigned)jj);
         };
-        // tile kt's index words of this lane: 4 x 16 B, plain loads into registers.  They are issued at the END of tile kt - 1 (behind that
-        // tile's DMA issue) and first used after the s_waitcnt vmcnt(0) at the top of tile kt, which waits for the ring slot anyway: hipcc's own
-        // vmcnt(0) in front of the first use (it cannot count the asm DMA) therefore costs nothing.  16 registers, live across the barrier only.
-        u32x4 iw[4];
-        auto load_idx = [&](int kt) __attribute__((always_inline)) {
-            if (!has_bias || !wave_active || (MODE == 2 && (dbg & (4 | 32)))) return;      // 32: no index loads (timing variant)
+        // the document's last, partial tile: rows past the document are clamped to its last row (and masked through the pair index /
+        // the tail mask)
+        auto issue_tail = [&](int kt, unsigned sbase, int jj) __attribute__((always_inline)) {
+            if (MODE == 2 && (dbg & 4)) return;
             if (MODE == 2 && (dbg & 16)) kt = 0;
-            const u32x4* p = reinterpret_cast<const u32x4*>(idx_base + (size_t)kt * 1024) + lane;
+            const int k0 = kt * KT;
+            const unsigned cj = 16u * (unsigned)(jj & 1) + 64u * (unsigned)((jj >> 1) & 1);
+            unsigned vd = vdma0;
+            asm volatile("" : "+v"(vd));
+            const unsigned long long base = (unsigned long long)(size_t)(kv_doc + (size_t)k0 * row_bytes);
+            const int lim = len - 1 - k0;
+            const int pr = (int)((unsigned)lane >> 4);
+            int r = 4 * (pstart + jj) + pr;
+            r = r < lim ? r : lim;
+            dma16((vd ^ cj) + (unsigned)(r - pr) * row_bytes, base, sbase + dst_wave + 1024u * (unsigned)jj);
+        };
+        auto issue_any = [&](int kt, unsigned sbase) __attribute__((always_inline)) {      // prologue and idle waves: one branch per tile
+            if ((kt + 1) * KT <= len) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) iw[i] = p[64 * i];
+                for (int jj = 0; jj < 4; ++jj) issue_full(kt, sbase, jj);
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) issue_tail(kt, sbase, jj);
+            }
         };
 
         HeadState st;
@@ -304,8 +320,9 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
         st.mref = kNegBig;
         st.l = 0.f;
 
-        // ---- softmax (lazy rescaling, 2^10 folded into the exponent) + O^T += V^T P^T on a finished score tile; Vs = LDS address of the V tile ----
-        auto softmax_pv = [&](f32x16& s, HeadState& st, const unsigned Vs) __attribute__((always_inline)) {
+        // ---- softmax (lazy rescaling, 2^10 folded into the exponent) + O^T += V^T P^T on a finished score tile; vs = this lane's V read
+        // base in the tile's ring slot (vbase + slot base) ----
+        auto softmax_pv = [&](f32x16& s, HeadState& st, const unsigned vs) __attribute__((always_inline)) {
             if (!(MODE == 2 && (dbg & 2))) {
                 float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
@@ -330,26 +347,35 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
                 st.l += psum;
             }
             if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
-            unsigned vb = vbase;
+            unsigned vb = vs;
             asm volatile("" : "+v"(vb));
             // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
             // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                f16x8 ph8, pl8;
+                // split of P: hi = f16(x) (v_cvt_pk_f16_f32), lo = f16(x - hi) by v_fma_mixlo / mixhi_f16 (fma(x, 1.0, -hi) in f32 -- exact --
+                // rounded to f16: the bits of cvt(x - float(hi)), one instruction per value instead of three per pair)
+                unsigned hw[4], lw[4];
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const f32x2 x = f32x2{s[8 * ks + j], s[8 * ks + j + 1]};
-                    const f16x2 h = __builtin_convertvector(x, f16x2);
-                    const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
-                    ph8[j] = h[0]; ph8[j + 1] = h[1];
-                    pl8[j] = l[0]; pl8[j + 1] = l[1];
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = s[8 * ks + 2 * j], x1 = s[8 * ks + 2 * j + 1];
+                    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+                    const unsigned hb = __builtin_bit_cast(unsigned, h);
+                    unsigned lb;
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(lb)
+                        : "v"(x0), "v"(x1), "v"(hb));
+                    hw[j] = hb;
+                    lw[j] = lb;
                 }
+                const u32x4 hq = {hw[0], hw[1], hw[2], hw[3]}, lq = {lw[0], lw[1], lw[2], lw[3]};
+                const f16x8 ph8 = __builtin_bit_cast(f16x8, hq), pl8 = __builtin_bit_cast(f16x8, lq);
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh) {
-                    // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vbase ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
+                    // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vb ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
                     auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
-                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(Vs + (vb ^ xorc) + addc));
+                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)((vb ^ xorc) + addc));
                     };
                     const h4 vh0 = trd(64u * dh, 4096u * ks);
                     const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
@@ -374,207 +400,132 @@ __global__ __launch_bounds__(256, WPS) void attention_idx_kernel(const AttnArgs 
             }
         };
 
-        // ---- one key tile out of ring slot `buf`; the DMA of tile kt + 1 is issued between the MFMAs -----------------------------------
-        auto compute = [&](int kt, const int buf, const bool more) __attribute__((always_inline)) {
-            const unsigned sbase = (unsigned)OFF_STAGE + (unsigned)buf * STAGE_BYTES;
-            const int k0 = kt * KT;
-            if (!wave_active) {
-                if (more) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) issue_kv(kt + 1, buf ^ 1, jj);
-                }
-                return;
+        const int n_kt = (len + KT - 1) / KT, n_full = len / KT;
+        const bool want_idx = BIAS && !(MODE == 2 && (dbg & (1 | 32)));
+        // index words of one key tile: four asm loads from a scalar tile pointer
+        const unsigned* idx_base = BIAS ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
+        u32x4 iw0 = {0u, 0u, 0u, 0u}, iw1 = iw0, iw2 = iw0, iw3 = iw0;
+        auto issue_idx = [&](int kt) __attribute__((always_inline)) {
+            const unsigned long long ib = sgpr64((unsigned long long)(size_t)idx_base + (unsigned long long)kt * 4096ull);
+            // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
+            // states, and nothing inside an asm string is padded by the compiler)
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                         : "+v"(iw0), "+v"(iw1), "+v"(iw2), "+v"(iw3)
+                         : "v"(ivoff), "s"(ib)
+                         : "memory");
+        };
+
+        // ---- prologue: tiles 0 and 1 into slots 0 and 1, the index words of tile 0 ----
+        issue_any(0, 0u);
+        if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
+        STAMP(6, tprev)
+
+        if (!wave_active) {
+            // a wave without queries of this item (the document's last query tile): its share of the DMA and the barriers, nothing else
+            unsigned sb2 = 2u * STAGE_BYTES;
+            for (int kt = 0; kt < n_kt; ++kt) {
+                if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
+                if (kt + 2 < n_kt) issue_any(kt + 2, sb2);
+                sb2 = sb2 == 2u * STAGE_BYTES ? 0u : sb2 + (unsigned)STAGE_BYTES;
             }
-            // bias = initial accumulator.  register e <-> key (e & 3) + 8 (e >> 2) + 4 hh of the tile; word e of the lane's index
-            f32x16 s;
-            if (!has_bias || (MODE == 2 && (dbg & 1))) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = 0.f;
-                if (!has_bias && k0 + KT > len) {         // no pair index (image-only model): mask the keys past the document here
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : 0.f;
-                }
+            continue;
+        }
+        if (want_idx) issue_idx(0);
+
+        // ---- one key tile out of ring slot `sb`; VAR says what is left to fetch (compile time: no branch, constant wait counts) ----
+        unsigned sb = 0u;                                    // byte base of the slot of tile kt; tile kt + 2 goes into the slot before it
+        auto tile = [&](auto var_tag, const int kt) __attribute__((always_inline)) {
+            constexpr int VAR = decltype(var_tag)::value;
+            constexpr bool more1 = VAR != V_LAST, issue2 = VAR == V_HOT || VAR == V_TAIL;
+            const unsigned sb2 = sb == 0u ? 2u * STAGE_BYTES : sb - (unsigned)STAGE_BYTES;
+            // tile kt has landed: everything but the youngest operations -- the four pieces of tile kt + 1 and the four index loads of this
+            // tile, issued after them -- is complete; then the barrier: everyone's pieces have, and everyone is done with tile kt - 1,
+            // whose slot tile kt + 2 goes into
+            if (want_idx) {
+                if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (p == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of 24 lookups in flight, not 48: register pressure
-                    const u32x4 w = iw[p];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const unsigned v = w[t];
-                        const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
-                        const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
-                        const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
-                        s[4 * p + t] = b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
-                    }
-                }
+                if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            STAMP(2, tprev)
-            // S^T tile: rows = keys (A operand from LDS), cols = queries (B operand = Q registers).  Chunk (2 st + hh) + 8 plane of row
-            // l31 sits at kbase ^ (32 st + 128 plane): one register + one v_xor per read instead of eight address registers
-            unsigned kb = kbase;
-            asm volatile("" : "+v"(kb));                  // opaque per tile: the XORs are recomputed, not hoisted into registers
-            // fragments one k-step ahead of the MFMAs, and no further: the scheduler would otherwise hoist all eight reads (32 registers)
-            f16x8 kh = lds_load<f16x8>(sbase + kb), kl = lds_load<f16x8>(sbase + (kb ^ 128u));
+            STAMP(0, tprev)
+            if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");      // 64: no barrier (timing variant: races)
+            STAMP(7, tprev)
+            // S^T = K Q^T from a zero accumulator; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            const unsigned kb = kbase + sb;
+            f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
 #pragma unroll
             for (int stp = 0; stp < 4; ++stp) {
                 f16x8 khn = kh, kln = kl;
                 if (stp < 3) {
-                    khn = lds_load<f16x8>(sbase + (kb ^ (32u * (stp + 1))));
-                    kln = lds_load<f16x8>(sbase + (kb ^ (32u * (stp + 1) + 128u)));
+                    khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
+                    kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
                 }
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
-                if (more) issue_kv(kt + 1, buf ^ 1, stp);    // next tile's DMA pieces ride in the shadow of the MFMAs
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
+                else asm volatile("" :: "v"(kl), "v"(kh));
+                if (VAR == V_HOT) issue_full(kt + 2, sb2, stp);
+                if (VAR == V_TAIL) issue_tail(kt + 2, sb2, stp);
+                if (!(MODE == 2 && (dbg & 128))) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                }
                 kh = khn;
                 kl = kln;
                 __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(3, tprev)
-            softmax_pv(s, st, sbase + TILE_BYTES);
-            if (more) load_idx(kt + 1);
-            STAMP(4, tprev)
-        };
-
-        const int n_kt = (len + KT - 1) / KT;
-        if constexpr (RING == 3) {
-            // ---- 3-deep ring, counted waits ----------------------------------------------------------------------------------------------
-            const unsigned long long ib0 = (unsigned long long)(size_t)idx_base;
-            const unsigned ivoff = 16u * (unsigned)lane;
-            const bool want_idx = wave_active && has_bias && !(MODE == 2 && (dbg & (1 | 32)));
-            // index words of one key tile: four asm loads (hand-counted, see above).  PF: the registers are carried around the loop (the words
-            // of tile kt + 1 are fetched as soon as the lookups of tile kt have consumed the registers, a whole softmax + P V + barrier + Q K^T
-            // ahead of their use), so they are read-write operands: input and output are then ONE register by construction and the loop's
-            // back edge needs no copy (a copy in front of the wait would read words that have not landed).
-            u32x4 iw0 = {0u, 0u, 0u, 0u}, iw1 = iw0, iw2 = iw0, iw3 = iw0;
-            auto issue_idx = [&](int kt) __attribute__((always_inline)) {
-                const unsigned long long ib = sgpr64(ib0 + (unsigned long long)kt * 4096ull);
-                // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
-                // states, and nothing inside an asm string is padded by the compiler)
-                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                             "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
-                             : "+v"(iw0), "+v"(iw1), "+v"(iw2), "+v"(iw3)
-                             : "v"(ivoff), "s"(ib)
-                             : "memory");
-            };
+            // bias: the index words are back when all but the pieces issued above are (they are older than those)
+            if (want_idx) {
+                // wait-only statements WITHOUT operands: naming the index registers here lets the register allocator copy them in front
+                // of the wait (seen in the .s: v_mov of words that had not landed).  The sched_barrier keeps their first use below it.
+                if (issue2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
-            if (n_kt > 1) {
+                for (int p = 0; p < 4; ++p) {
+                    if (p == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of 24 lookups in flight, not 48: register pressure
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) issue_kv(1, 1, jj);
-            }
-            if (PF && want_idx) issue_idx(0);
-            STAMP(6, tprev)
-            int slot = 0;
-            for (int kt = 0; kt < n_kt; ++kt) {
-                const bool more1 = kt + 1 < n_kt, more2 = kt + 2 < n_kt;
-                // tile kt has landed: everything but the youngest operations -- the four pieces of tile kt + 1 and (PF) the four index loads
-                // of this tile, issued after them -- is complete; then the barrier: everyone's pieces have, and everyone is done with tile
-                // kt - 1, whose slot tile kt + 2 goes into
-                if (PF && want_idx) {
-                    if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                STAMP(0, tprev)
-                // not PF: this tile's index words are issued in front of the barrier (its wait covers part of their latency) and BEFORE the DMA
-                // pieces of tile kt + 2, so that the counted wait behind the Q K^T MFMAs covers them
-                if (!PF && want_idx) issue_idx(kt);
-                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");      // 64: no barrier (timing variant: races)
-                STAMP(7, tprev)
-                const int slot2 = slot == 0 ? 2 : slot - 1;       // (slot + 2) % 3
-                if (!wave_active) {
-                    if (more2) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) issue_kv(kt + 2, slot2, jj);
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned v = iw[p][t];
+                        const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
+                        const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
+                        const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
+                        s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
                     }
-                    slot = slot == 2 ? 0 : slot + 1;
-                    continue;
                 }
+                if (more1) {                     // the registers are free: fetch the next tile's words under this tile's softmax and P V
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_idx(kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (!BIAS && VAR == V_LAST) {          // no pair index (image-only model): mask the keys past the document here
                 const int k0 = kt * KT;
-                const unsigned sbase = (unsigned)OFF_STAGE + (unsigned)slot * STAGE_BYTES;
-                // S^T = K Q^T from a zero accumulator; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them.
-                // (kbase + sbase) ^ c == (kbase ^ c) + sbase: c touches bits 5-7, sbase bits >= 10
-                f32x16 s;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = 0.f;
-                const unsigned kb = kbase + sbase;
-                f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
-#pragma unroll
-                for (int stp = 0; stp < 4; ++stp) {
-                    f16x8 khn = kh, kln = kl;
-                    if (stp < 3) {
-                        khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
-                        kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
-                    }
-                    if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
-                    else asm volatile("" :: "v"(kl), "v"(kh));
-                    if (more2) issue_kv(kt + 2, slot2, stp);
-                    if (!(MODE == 2 && (dbg & 128))) {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
-                    }
-                    kh = khn;
-                    kl = kln;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                STAMP(3, tprev)
-                // bias: the index words are back when all but the pieces issued above are (they are older than those)
-                if (want_idx) {
-                    // wait-only statements WITHOUT operands: naming the index registers here lets the register allocator copy them in front
-                    // of the wait (seen in the .s: v_mov of words that had not landed).  The sched_barrier keeps their first use below it.
-                    if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        if (p == 2) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const unsigned v = iw[p][t];
-                            const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
-                            const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
-                            const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
-                            s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
-                        }
-                    }
-                    if (PF && more1) {               // the registers are free: fetch the next tile's words under this tile's softmax and P V
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_idx(kt + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (!has_bias && k0 + KT > len) {
+                if (k0 + KT > len) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : s[e];
                 }
-                STAMP(2, tprev)
-                softmax_pv(s, st, sbase + TILE_BYTES);
-                STAMP(4, tprev)
-                slot = slot == 2 ? 0 : slot + 1;
             }
-        } else {
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) issue_kv(0, 0, jj);
-        load_idx(0);
-        STAMP(6, tprev)                                // item prologue: queue, tables, Q fragments, first DMA issue
-        for (int kt = 0; kt < n_kt; kt += 2) {
-            // my pieces of tile kt have landed, then the barrier: everyone's have, and everyone is done with tile kt - 1,
-            // whose ring slot the DMA issued during this tile overwrites
-            if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(0, tprev) asm volatile("s_barrier" ::: "memory"); STAMP(7, tprev) }
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            compute(kt, 0, kt + 1 < n_kt);
-            if (kt + 1 >= n_kt) break;
-            if (DIAG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); STAMP(0, tprev) asm volatile("s_barrier" ::: "memory"); STAMP(7, tprev) }
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            compute(kt + 1, 1, kt + 2 < n_kt);
-        }
+            STAMP(2, tprev)
+            softmax_pv(s, st, vbase + sb);
+            STAMP(4, tprev)
+            sb = sb == 2u * STAGE_BYTES ? 0u : sb + (unsigned)STAGE_BYTES;
+        };
+        {
+            int kt = 0;
+            for (; kt + 2 < n_full; ++kt) tile(std::integral_constant<int, V_HOT>{}, kt);           // tile kt + 2 is a whole tile
+            if (kt + 2 < n_kt) { tile(std::integral_constant<int, V_TAIL>{}, kt); ++kt; }            // ... is the partial last tile
+            if (kt + 1 < n_kt) { tile(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
+            tile(std::integral_constant<int, V_LAST>{}, kt);
         }
 
-        if (wave_active) {
+        {
             const float l_tot = st.l + __shfl_xor(st.l, 32, 64);   // the two lane halves hold disjoint keys
             const float inv = 1.0f / (l_tot * a.qkv_scale);        // the 2^10 of the probabilities is in l as well
             if (qi < len) {
@@ -605,55 +556,49 @@ bool attention_idx_supports(const AttnArgs& a) {
     return a.ctx_split && (a.pair_idx == nullptr || (a.bins1 >= 1 && a.bins1 <= BINS_MAX && a.bins2 >= 1 && a.bins2 <= BINS_MAX));
 }
 
-// a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked
-template <int RING, bool PF, int WPS = WGS>
-static void launch_idx_ring(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
-    constexpr int lds = OFF_STAGE + RING * STAGE_BYTES;
-    static_assert(WPS * lds <= 160 * 1024, "LDS budget");
+template <bool BIAS>
+static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #ifdef MMEE_DIAG
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, RING, PF, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #endif
         attr_set = true;
     }
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
-    int grid = WPS * num_cus;
+    int grid = WGS * num_cus;
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
-#ifdef MMEE_DIAG
-    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, stamps, 0); return; }
-    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, dbg); return; }
+#ifdef MMEE_DIAG      // stamped build and timing variants (wrong results): diagnostic library only
+    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
 #endif
     (void)stamps; (void)dbg;
-    hipLaunchKernelGGL((attention_idx_kernel<0, RING, PF, WPS>), dim3(grid), dim3(256), lds, s, a, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
 }
 
-// The release library runs ONE form: 3-deep ring, index words prefetched a tile ahead.  The diagnostic library (make diag, -DMMEE_DIAG)
-// also carries the stamped build (MMEE_ATTN_STAMPS=1), the timing variants (MMEE_ATTN_DBG=<bits>, wrong results), the double-buffered
-// ring (MMEE_ATTN_RING=2) and the form without index prefetch (MMEE_ATTN_PF=0) for A/B measurements.
+// a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
+// The release library runs ONE form of the kernel.  The diagnostic library (make diag, -DMMEE_DIAG) also carries the stamped build
+// (MMEE_ATTN_STAMPS=1) and the timing variants (MMEE_ATTN_DBG=<bits>, wrong results).
 void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
+    unsigned long long* stamps = nullptr;
+    int dbg = 0;
 #ifdef MMEE_DIAG
-    static unsigned long long* stamps = [] {
+    static unsigned long long* stamps_buf = [] {
         unsigned long long* p = nullptr;
         if (diag_env_int("MMEE_ATTN_STAMPS", 0) == 1 && hipMalloc((void**)&p, 64) == hipSuccess) (void)hipMemset(p, 0, 64);
         return p;
     }();
-    static const int dbg = diag_env_int("MMEE_ATTN_DBG", 0);
-    static const int ring = diag_env_int("MMEE_ATTN_RING", 3);
-    static const int pf = diag_env_int("MMEE_ATTN_PF", 1);
+    static const int dbg_env = diag_env_int("MMEE_ATTN_DBG", 0);
+    stamps = stamps_buf;
+    dbg = dbg_env;
     g_attn_idx_stamps = stamps;
-    static const int wps = diag_env_int("MMEE_ATTN_WPS", 3);       // 2: two workgroups per CU (256 VGPRs per wave), occupancy A/B
-    if (ring == 2) { launch_idx_ring<2, false>(a, max_docs, num_cus, stamps, dbg, s); return; }
-    if (wps == 2) { launch_idx_ring<3, true, 2>(a, max_docs, num_cus, stamps, dbg, s); return; }
-    if (!pf) { launch_idx_ring<3, false>(a, max_docs, num_cus, stamps, dbg, s); return; }
-    launch_idx_ring<3, true>(a, max_docs, num_cus, stamps, dbg, s);
-#else
-    launch_idx_ring<3, true>(a, max_docs, num_cus, nullptr, 0, s);
 #endif
+    if (a.pair_idx) launch_idx<true>(a, max_docs, num_cus, stamps, dbg, s);
+    else launch_idx<false>(a, max_docs, num_cus, stamps, dbg, s);
 }
 
 }  // namespace mmee

@@ -147,14 +147,37 @@ def test_criterion_head_strategy_matrix_matches_golden(pkg, name, precision):
         np.testing.assert_allclose(_np(out.all_logits), g["logits_store"], rtol=0, atol=tol)
         np.testing.assert_allclose(_np(out.head_crit), g["exit_crit"], rtol=0, atol=2e-5 * scale)
     store = g["logits_store"]
-    for i in range(4):
-        thr = float(g[f"pol_thr{i}"])
-        if not (thr == 0.0 or thr > 1.0 or _margin_ok(store, thr, 1e-5)):
-            continue
+    if str(cfg.exit_config.inference_strategy) == "entropy":
+        # the fast path leaves at the first exit whose criterion passes its threshold with the criterion's own sign: entropy BELOW the
+        # threshold (EarlyExitInference.get_sign -> operator.lt, EE/models/EE_modules.py:137-144), in float64 on the float32 logits like
+        # the max-confidence test.  Thresholds in the widest gap of every exit's entropies.
+        x = store.astype(np.float64)
+        ent = np.log(np.exp(x).sum(-1)) - (x * np.exp(x)).sum(-1) / np.exp(x).sum(-1)           # EE/models/EE_modules.py:149-154
+        E1 = ent.shape[0]
+        thr = np.zeros(E1)
+        margin = 1e-4 * max(1.0, float(np.abs(ent).max()))
+        for e in range(E1):
+            srt = np.sort(ent[e])
+            k = int(np.argmax(np.diff(srt)))
+            thr[e] = 0.5 * (srt[k] + srt[k + 1]) if srt[k + 1] - srt[k] > 4 * margin else -1.0      # no clear gap: nobody leaves here
+        assert np.abs(ent - thr[:, None]).min() > margin
+        hit = ent < thr[:, None]
+        hit[-1] = True
+        ex = hit.argmax(0).astype(np.int32)
         for kw in (dict(), dict(whole_layers=True), dict(probe_always=True)):
             out = eng.forward(*args, thresholds=thr, **kw)
-            assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"]), (name, precision, thr, kw)
-            np.testing.assert_allclose(_np(out.logits), g[f"pol_pred{i}"], rtol=0, atol=tol)
+            assert np.array_equal(_np(out.exit_layer), ex), (name, precision, kw)
+            np.testing.assert_allclose(_np(out.logits), store[ex, np.arange(n_docs)], rtol=0, atol=tol)
+        assert len(np.unique(ex)) >= 2
+    else:
+        for i in range(4):
+            thr = float(g[f"pol_thr{i}"])
+            if not (thr == 0.0 or thr > 1.0 or _margin_ok(store, thr, 1e-5)):
+                continue
+            for kw in (dict(), dict(whole_layers=True), dict(probe_always=True)):
+                out = eng.forward(*args, thresholds=thr, **kw)
+                assert np.array_equal(_np(out.exit_layer), g[f"pol_exits{i}"]), (name, precision, thr, kw)
+                np.testing.assert_allclose(_np(out.logits), g[f"pol_pred{i}"], rtol=0, atol=tol)
     eng.close()
 
 
