@@ -150,7 +150,13 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 // vmcnt(0) at the first use of a compiler-visible load while an LDS-DMA is pending).
 enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 
-template <int MODE, bool BIAS>
+// XP: experiment bits kept as template switches while they are being measured (tools/attn_ab.sh, MMEE_ATTN_XP in the diagnostic library):
+//   1 = a queue ticket is TWO consecutive items (two query tiles of one (document, head): same K / V rows from L2, same bucket tables),
+//   2 = bias first: the lookups initialise the score accumulator (two adds per score instead of three, no zero init, no mid-tile wait;
+//       the index words of tile kt + 1 are fetched right behind the lookups of tile kt, before the DMA of tile kt + 2),
+//   4 = the eight XOR-ed V fragment addresses of a tile are computed once and used by both k-steps.
+constexpr int kXP = 0;
+template <int MODE, bool BIAS, int XP>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -197,19 +203,32 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
     const unsigned kbase = img_off(l31, hh);
     const unsigned ivoff = 16u * (unsigned)lane;
 
+    constexpr int TICKET = (XP & 1) ? 2 : 1;             // items per queue ticket
+    int t_left = 0, t_next = 0, t_queue = 0;             // rest of the current ticket
     for (;; item += gridDim.x) {
         int doc, head, qt;
         if (a.item_counter) {
             bool got = false;
+            const int per_doc = a.heads * qtiles;
             while (q_try < 8) {
-                const int q = (my_xcd + q_try) & 7;
-                __syncthreads();                       // everyone has read the previous slot value
-                if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
-                __syncthreads();
-                const int j = __builtin_amdgcn_readfirstlane(*q_slot);     // wave-uniform by construction: keep doc / head / tile scalar
+                int q, j;
+                if (t_left > 0) {                      // second item of the ticket
+                    q = t_queue;
+                    j = t_next;
+                    --t_left;
+                } else {
+                    q = (my_xcd + q_try) & 7;
+                    __syncthreads();                   // everyone has read the previous slot value
+                    if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
+                    __syncthreads();
+                    j = TICKET * __builtin_amdgcn_readfirstlane(*q_slot);     // wave-uniform by construction: keep doc / head / tile scalar
+                    t_left = TICKET - 1;
+                    t_next = j;
+                    t_queue = q;
+                }
+                t_next = j + 1;
                 // queue q serves the documents q, q + 8, ...; within a document the order is head-major, query tile fastest: the 12-16
                 // heads of a document follow each other on ONE XCD, so its pair index (shared by all heads) is fetched into that L2 once
-                const int per_doc = a.heads * qtiles;
                 const int dl = j / per_doc;
                 const int r = j - dl * per_doc;
                 const int dq = q + 8 * dl;
@@ -220,6 +239,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                     got = true;
                     break;
                 }
+                t_left = 0;                            // past the queue's last document: next queue
                 ++q_try;
             }
             if (!got) break;
@@ -349,6 +369,11 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
             unsigned vb = vs;
             asm volatile("" : "+v"(vb));
+            unsigned va[8];                               // XP & 4: vb ^ (64 dh + 128 plane + 32 x), index 4 dh + 2 plane + x
+            if (XP & 4) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) va[c] = vb ^ (64u * (unsigned)(c >> 2) + 128u * (unsigned)((c >> 1) & 1) + 32u * (unsigned)(c & 1));
+            }
             // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
             // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
 #pragma unroll
@@ -375,7 +400,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 for (int dh = 0; dh < 2; ++dh) {
                     // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vb ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
                     auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
-                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)((vb ^ xorc) + addc));
+                        const unsigned ad = (XP & 4) ? va[4 * ((xorc >> 6) & 1) + 2 * ((xorc >> 7) & 1) + ((xorc >> 5) & 1)] : (vb ^ xorc);
+                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(ad + addc));
                     };
                     const h4 vh0 = trd(64u * dh, 4096u * ks);
                     const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
@@ -416,8 +442,234 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                          : "memory");
         };
 
+        if constexpr ((XP & 8) != 0) {
+        // =================================================================================================================
+        // XP & 8: SOFTWARE-PIPELINED tiles.  The matrix pipe is hidden behind the vector / LDS instruction stream (header), and a wave's
+        // dependent MFMA chains (12 for Q K^T, 2 x 6 for P V) leave ~24 issue cycles between consecutive MFMAs that only THIS wave's
+        // independent instructions can use.  So one iteration pairs, in one basic block each,
+        //     Q K^T of tile kt + 1  (matrix)  with  exp / row sum / f16 split of tile kt  (vector), and
+        //     P V of tile kt        (matrix)  with  the bias lookups + adds of tile kt + 1 (vector + LDS);
+        // the scores of tile kt + 1 are complete when the iteration ends.  The rare "move the reference maximum" branch sits in front of
+        // the first block.  Ring discipline: tile kt + 1 must have landed at the TOP of iteration kt (one iteration after its DMA was
+        // issued), tile kt + 2 goes into the slot of tile kt - 1 behind the iteration's barrier.  Barriers: one in the prologue and one
+        // per iteration that has a next tile, the same count as the plain loop; idle waves follow the same schedule.
+        // =================================================================================================================
+        issue_any(0, 0u);
+        if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
+        STAMP(6, tprev)
+        if (!wave_active) {
+            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
+            unsigned sbp = 2u * STAGE_BYTES;             // slot of tile kt - 1 = slot of tile kt + 2
+            for (int kt = 0; kt + 1 < n_kt; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt + 1 (nothing younger is in flight)
+                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
+                if (kt + 2 < n_kt) issue_any(kt + 2, sbp);
+                sbp = sbp == 2u * STAGE_BYTES ? 0u : sbp + (unsigned)STAGE_BYTES;
+            }
+            continue;
+        }
+        if (want_idx) issue_idx(0);
+        // Q K^T of one tile out of the slot at `sbk`, from a zero accumulator; VAR says which DMA pieces ride between the MFMAs
+        auto qk_chain = [&](auto var_tag, f32x16& s, const unsigned sbk, const int kt2, const unsigned sb2) __attribute__((always_inline)) {
+            constexpr int VAR = decltype(var_tag)::value;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            const unsigned kb = kbase + sbk;
+            f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
+#pragma unroll
+            for (int stp = 0; stp < 4; ++stp) {
+                f16x8 khn = kh, kln = kl;
+                if (stp < 3) {
+                    khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
+                    kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
+                }
+                if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
+                else asm volatile("" :: "v"(kl), "v"(kh));
+                if (VAR == V_HOT) issue_full(kt2, sb2, stp);
+                if (VAR == V_TAIL) issue_tail(kt2, sb2, stp);
+                if (!(MODE == 2 && (dbg & 128))) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
+                }
+                kh = khn;
+                kl = kln;
+            }
+        };
+        auto bias_add = [&](f32x16& s) __attribute__((always_inline)) {
+            const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned v = iw[p][t];
+                    const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
+                    const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
+                    const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
+                    s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
+                }
+            }
+        };
+        auto tail_mask = [&](f32x16& s, const int kt) __attribute__((always_inline)) {      // image-only model: keys past the document
+            const int k0 = kt * KT;
+            if (k0 + KT > len) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : s[e];
+            }
+        };
+        // ---- tile 0's scores ----
+        if (want_idx) {
+            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        STAMP(0, tprev)
+        if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
+        STAMP(7, tprev)
+        f32x16 s_cur;
+        qk_chain(std::integral_constant<int, V_LAST>{}, s_cur, 0u, 0, 0u);
+        if (want_idx) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            bias_add(s_cur);
+            if (n_kt > 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_idx(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (!BIAS) tail_mask(s_cur, 0);
+        STAMP(3, tprev)
+
+        unsigned sb = 0u;                                    // slot of tile kt
+        auto iter = [&](auto var_tag, const int kt) __attribute__((always_inline)) {
+            constexpr int VAR = decltype(var_tag)::value;
+            constexpr bool more1 = VAR != V_LAST, issue2 = VAR == V_HOT || VAR == V_TAIL;
+            const unsigned sb1 = sb == 2u * STAGE_BYTES ? 0u : sb + (unsigned)STAGE_BYTES;      // slot of tile kt + 1
+            const unsigned sb2 = sb == 0u ? 2u * STAGE_BYTES : sb - (unsigned)STAGE_BYTES;      // slot of tile kt - 1 = of tile kt + 2
+            if (more1) {
+                // tile kt + 1 has landed: only this wave's index loads of tile kt + 1 (issued after its pieces) may still be in flight
+                if (want_idx) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                STAMP(0, tprev)
+                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
+                STAMP(7, tprev)
+            }
+            // reference maximum of tile kt (lazy: moves only when exceeded by 2^5), before the paired blocks
+            const bool do_sm = !(MODE == 2 && (dbg & 2));
+            if (do_sm) {
+                float tmax = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
+#pragma unroll
+                for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, s_cur[e]), s_cur[e + 1]);
+                tmax = fmaxf(tmax, s_cur[15]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                if (__any(tmax > st.mref + lazy)) {
+                    const float mnew = fmaxf(st.mref, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((st.mref - mnew) * cexp);
+                    st.mref = mnew;
+                    st.l *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
+                }
+            }
+            // ---- block 1: Q K^T of tile kt + 1 (matrix)  ||  exp, row sum, f16 split of tile kt (vector) ----
+            f32x16 s_nxt;
+            if (more1) qk_chain(var_tag, s_nxt, sb1, kt + 2, sb2);
+            unsigned hw[8], lw[8];
+            if (do_sm) {
+                const float negm = kPShift - st.mref * cexp;
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s_cur[e] = __builtin_amdgcn_exp2f(fmaf(s_cur[e], cexp, negm));      // 2^10 p, p relative to the reference maximum
+                    psum += s_cur[e];
+                }
+                st.l += psum;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {      // split of P: hi = f16(x), lo = f16(x - hi) by v_fma_mixlo / mixhi_f16
+                const float x0 = s_cur[2 * j], x1 = s_cur[2 * j + 1];
+                const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+                const unsigned hb = __builtin_bit_cast(unsigned, h);
+                unsigned lb;
+                asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                    "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                    : "=&v"(lb)
+                    : "v"(x0), "v"(x1), "v"(hb));
+                hw[j] = hb;
+                lw[j] = lb;
+            }
+            STAMP(3, tprev)
+            // ---- block 2: P V of tile kt (matrix)  ||  bias of tile kt + 1 (vector + LDS) ----
+            if (more1 && want_idx) {
+                // the index words of tile kt + 1 are back when all but the pieces of tile kt + 2 issued above are (they are older)
+                if (issue2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(MODE == 2 && (dbg & 8))) {
+                const unsigned vb = vbase + sb;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4 hq = {hw[4 * ks], hw[4 * ks + 1], hw[4 * ks + 2], hw[4 * ks + 3]};
+                    const u32x4 lq = {lw[4 * ks], lw[4 * ks + 1], lw[4 * ks + 2], lw[4 * ks + 3]};
+                    const f16x8 ph8 = __builtin_bit_cast(f16x8, hq), pl8 = __builtin_bit_cast(f16x8, lq);
+#pragma unroll
+                    for (int dh = 0; dh < 2; ++dh) {
+                        auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
+                            return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)((vb ^ xorc) + addc));
+                        };
+                        const h4 vh0 = trd(64u * dh, 4096u * ks);
+                        const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
+                        const h4 vl0 = trd(64u * dh + 128u, 4096u * ks);
+                        const h4 vl1 = trd(64u * dh + 128u + 32u, 4096u * ks + 2048u);
+                        f16x8 vh, vl;
+                        const f16x4 a0 = __builtin_bit_cast(f16x4, vh0), a1 = __builtin_bit_cast(f16x4, vh1);
+                        const f16x4 b0 = __builtin_bit_cast(f16x4, vl0), b1 = __builtin_bit_cast(f16x4, vl1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
+                        if (dh == 0) {
+                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
+                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
+                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
+                        } else {
+                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
+                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
+                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                asm volatile("" :: "v"(hw[0]), "v"(lw[3]), "v"(hw[5]), "v"(lw[7]));
+            }
+            if (more1) {
+                if (want_idx) {
+                    bias_add(s_nxt);
+                    if (issue2) {                 // the registers are free: the words of tile kt + 2
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_idx(kt + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (!BIAS) tail_mask(s_nxt, kt + 1);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_cur[e] = s_nxt[e];
+            }
+            STAMP(4, tprev)
+            sb = sb1;
+        };
+        {
+            int kt = 0;
+            for (; kt + 2 < n_full; ++kt) iter(std::integral_constant<int, V_HOT>{}, kt);           // tile kt + 2 is a whole tile
+            if (kt + 2 < n_kt) { iter(std::integral_constant<int, V_TAIL>{}, kt); ++kt; }            // ... is the partial last tile
+            if (kt + 1 < n_kt) { iter(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
+            iter(std::integral_constant<int, V_LAST>{}, kt);
+        }
+        } else {
         // ---- prologue: tiles 0 and 1 into slots 0 and 1, the index words of tile 0 ----
         issue_any(0, 0u);
+        if ((XP & 2) && wave_active && want_idx) issue_idx(0);      // bias first: the index words of a tile are older than the DMA of the tile after it
         if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
         STAMP(6, tprev)
 
@@ -433,7 +685,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             }
             continue;
         }
-        if (want_idx) issue_idx(0);
+        if (!(XP & 2) && want_idx) issue_idx(0);
 
         // ---- one key tile out of ring slot `sb`; VAR says what is left to fetch (compile time: no branch, constant wait counts) ----
         unsigned sb = 0u;                                    // byte base of the slot of tile kt; tile kt + 2 goes into the slot before it
@@ -444,20 +696,47 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             // tile kt has landed: everything but the youngest operations -- the four pieces of tile kt + 1 and the four index loads of this
             // tile, issued after them -- is complete; then the barrier: everyone's pieces have, and everyone is done with tile kt - 1,
             // whose slot tile kt + 2 goes into
-            if (want_idx) {
+            constexpr bool BF = (XP & 2) != 0;            // bias first
+            if (want_idx && !BF) {
                 if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
+            } else {      // bias first: the youngest four operations are the pieces of tile kt + 1; this tile's index words are older
                 if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             STAMP(0, tprev)
             if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");      // 64: no barrier (timing variant: races)
             STAMP(7, tprev)
-            // S^T = K Q^T from a zero accumulator; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them
             f32x16 s;
+            auto lookups = [&](bool init) __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+                for (int p = 0; p < 4; ++p) {
+                    if (p == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of 24 lookups in flight, not 48: register pressure
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned v = iw[p][t];
+                        const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
+                        const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
+                        const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
+                        const float b = b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
+                        if (init) s[4 * p + t] = b;
+                        else s[4 * p + t] += b;
+                    }
+                }
+                if (more1) {                     // the registers are free: fetch the next tile's words
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_idx(kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (want_idx && BF) lookups(true);            // the bias IS the initial accumulator: the matrix pipe adds it to the scores
+            else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            }
+            // S^T = K Q^T; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them
             const unsigned kb = kbase + sb;
             f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
 #pragma unroll
@@ -480,31 +759,13 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(3, tprev)
-            // bias: the index words are back when all but the pieces issued above are (they are older than those)
-            if (want_idx) {
+            // bias behind the Q K^T MFMAs: the index words are back when all but the pieces issued above are (they are older than those)
+            if (want_idx && !BF) {
                 // wait-only statements WITHOUT operands: naming the index registers here lets the register allocator copy them in front
                 // of the wait (seen in the .s: v_mov of words that had not landed).  The sched_barrier keeps their first use below it.
                 if (issue2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if (p == 2) __builtin_amdgcn_sched_barrier(0);      // two groups of 24 lookups in flight, not 48: register pressure
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const unsigned v = iw[p][t];
-                        const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
-                        const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
-                        const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
-                        s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
-                    }
-                }
-                if (more1) {                     // the registers are free: fetch the next tile's words under this tile's softmax and P V
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_idx(kt + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                lookups(false);
             } else if (!BIAS && VAR == V_LAST) {          // no pair index (image-only model): mask the keys past the document here
                 const int k0 = kt * KT;
                 if (k0 + KT > len) {
@@ -524,6 +785,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (kt + 1 < n_kt) { tile(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
             tile(std::integral_constant<int, V_LAST>{}, kt);
         }
+        }      // plain / pipelined loop
 
         {
             const float l_tot = st.l + __shfl_xor(st.l, 32, 64);   // the two lane halves hold disjoint keys
@@ -556,14 +818,14 @@ bool attention_idx_supports(const AttnArgs& a) {
     return a.ctx_split && (a.pair_idx == nullptr || (a.bins1 >= 1 && a.bins1 <= BINS_MAX && a.bins2 >= 1 && a.bins2 <= BINS_MAX));
 }
 
-template <bool BIAS>
+template <bool BIAS, int XP>
 static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #ifdef MMEE_DIAG
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #endif
         attr_set = true;
     }
@@ -573,16 +835,16 @@ static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned lo
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
 #ifdef MMEE_DIAG      // stamped build and timing variants (wrong results): diagnostic library only
-    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
-    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
+    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
 #endif
     (void)stamps; (void)dbg;
-    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
 }
 
 // a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
 // The release library runs ONE form of the kernel.  The diagnostic library (make diag, -DMMEE_DIAG) also carries the stamped build
-// (MMEE_ATTN_STAMPS=1) and the timing variants (MMEE_ATTN_DBG=<bits>, wrong results).
+// (MMEE_ATTN_STAMPS=1), the timing variants (MMEE_ATTN_DBG=<bits>, wrong results) and the experiment forms (MMEE_ATTN_XP=<bits>).
 void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
     unsigned long long* stamps = nullptr;
     int dbg = 0;
@@ -593,12 +855,25 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         return p;
     }();
     static const int dbg_env = diag_env_int("MMEE_ATTN_DBG", 0);
+    static const int xp = diag_env_int("MMEE_ATTN_XP", kXP);
     stamps = stamps_buf;
     dbg = dbg_env;
     g_attn_idx_stamps = stamps;
+    if (a.pair_idx && xp != kXP) {
+        switch (xp) {
+            case 0: launch_idx<true, 0>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 1: launch_idx<true, 1>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 2: launch_idx<true, 2>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 4: launch_idx<true, 4>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 6: launch_idx<true, 6>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 7: launch_idx<true, 7>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 8: launch_idx<true, 8>(a, max_docs, num_cus, stamps, dbg, s); return;
+            default: break;
+        }
+    }
 #endif
-    if (a.pair_idx) launch_idx<true>(a, max_docs, num_cus, stamps, dbg, s);
-    else launch_idx<false>(a, max_docs, num_cus, stamps, dbg, s);
+    if (a.pair_idx) launch_idx<true, kXP>(a, max_docs, num_cus, stamps, dbg, s);
+    else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);
 }
 
 }  // namespace mmee

@@ -207,3 +207,15 @@ def test_local_processor_loader(pkg, tmp_path):
     assert got is not None and hasattr(got, "tokenizer")
     enc = got.tokenizer(["hi", "hi"], boxes=[[1, 2, 3, 4], [5, 6, 7, 8]], padding="max_length", max_length=8, truncation=True)
     assert len(enc["input_ids"]) == 8 and enc["input_ids"][0] == 0
+
+
+def test_attention_index_loads_stay_untouched_until_their_wait():
+    """The attention kernel's pair-index loads are inline-asm loads whose registers only become valid at a hand-counted s_waitcnt; a
+    compiler-made copy, spill or reuse of those registers in between would read or clobber words in flight.  tools/check_attn_asm.py
+    compiles the kernel to assembly and walks its control-flow graph (no GPU needed)."""
+    import subprocess, sys, os
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_attn_asm.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "ok" in r.stdout
