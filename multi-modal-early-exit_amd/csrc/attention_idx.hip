@@ -54,6 +54,7 @@ constexpr float kLazyLog2 = 5.0f;             // the running maximum lags by at 
 
 typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned img_off(int row, int ch) {     // byte offset of 16-byte chunk ch (0..15) of a tile row
     return 256u * (unsigned)row + 16u * ((unsigned)ch ^ ((((unsigned)row & 3u) << 2) | (((unsigned)row >> 2) & 3u)));
@@ -151,11 +152,14 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 
 // XP: experiment bits kept as template switches while they are being measured (tools/attn_ab.sh, MMEE_ATTN_XP in the diagnostic library):
-//   1 = a queue ticket is TWO consecutive items (two query tiles of one (document, head): same K / V rows from L2, same bucket tables),
 //   2 = bias first: the lookups initialise the score accumulator (two adds per score instead of three, no zero init, no mid-tile wait;
 //       the index words of tile kt + 1 are fetched right behind the lookups of tile kt, before the DMA of tile kt + 2),
-//   4 = the eight XOR-ed V fragment addresses of a tile are computed once and used by both k-steps.
-constexpr int kXP = 0;
+// Measured and removed (round 3, tools/attn_ab.sh on 256 documents x 12 layers, baseline 10.1 ms; bias first 9.9 ms): two-item tickets
+// 10.5 ms, eight precomputed V fragment addresses 10.0 ms, software-pipelined tiles (Q K^T of tile kt + 1 paired with the exp / split of
+// tile kt, P V of tile kt with the lookups of tile kt + 1, in one basic block each) 10.1 ms at 168 VGPRs + 18 spilled, K / V DMA and Q
+// loads ahead of the table fill with no drain in front 9.9 ms (no change), the next queue ticket drawn at the start of an item 10.4 ms
+// (a held ticket starts late: the queue balances worse).
+constexpr int kXP = 2;
 template <int MODE, bool BIAS, int XP>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
@@ -203,30 +207,19 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
     const unsigned kbase = img_off(l31, hh);
     const unsigned ivoff = 16u * (unsigned)lane;
 
-    constexpr int TICKET = (XP & 1) ? 2 : 1;             // items per queue ticket
-    int t_left = 0, t_next = 0, t_queue = 0;             // rest of the current ticket
     for (;; item += gridDim.x) {
+        unsigned long long t_item = 0;
+        if (DIAG) t_item = stamp_now();
         int doc, head, qt;
         if (a.item_counter) {
             bool got = false;
             const int per_doc = a.heads * qtiles;
             while (q_try < 8) {
-                int q, j;
-                if (t_left > 0) {                      // second item of the ticket
-                    q = t_queue;
-                    j = t_next;
-                    --t_left;
-                } else {
-                    q = (my_xcd + q_try) & 7;
-                    __syncthreads();                   // everyone has read the previous slot value
-                    if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
-                    __syncthreads();
-                    j = TICKET * __builtin_amdgcn_readfirstlane(*q_slot);     // wave-uniform by construction: keep doc / head / tile scalar
-                    t_left = TICKET - 1;
-                    t_next = j;
-                    t_queue = q;
-                }
-                t_next = j + 1;
+                const int q = (my_xcd + q_try) & 7;
+                __syncthreads();                       // everyone has read the previous slot value
+                if (tid == 0) *q_slot = atomicAdd(a.item_counter + 16 * q, 1);
+                __syncthreads();
+                const int j = __builtin_amdgcn_readfirstlane(*q_slot);     // wave-uniform by construction: keep doc / head / tile scalar
                 // queue q serves the documents q, q + 8, ...; within a document the order is head-major, query tile fastest: the 12-16
                 // heads of a document follow each other on ONE XCD, so its pair index (shared by all heads) is fetched into that L2 once
                 const int dl = j / per_doc;
@@ -239,7 +232,6 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                     got = true;
                     break;
                 }
-                t_left = 0;                            // past the queue's last document: next queue
                 ++q_try;
             }
             if (!got) break;
@@ -257,20 +249,23 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         const int q0 = qt * QT;
         if (q0 >= qlen) continue;                      // uniform over the workgroup
         unsigned long long tprev = 0;
-        if (DIAG) tprev = stamp_now();
+        if (DIAG) { tprev = stamp_now(); ph[1] += tprev - t_item; }      // queue ticket + document offsets
 
         __syncthreads();                               // previous item's LDS reads are done
-        if (BIAS && head != cur_head) {                // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
-            float* T1 = reinterpret_cast<float*>(smem + OFF_T1);
-            float* TX = reinterpret_cast<float*>(smem + OFF_TX);
-            float* TY = reinterpret_cast<float*>(smem + OFF_TY);
-            const float f = a.inv_sqrt_d * sc2;
-            if (tid < a.bins1) T1[tid] = a.w1[(size_t)head * a.bins1 + tid] * f;
-            if (tid == a.bins1) T1[tid] = kNegBig;
-            if (tid >= 64 && tid < 64 + a.bins2) TX[tid - 64] = a.wx[(size_t)head * a.bins2 + tid - 64] * f;
-            if (tid >= 128 && tid < 128 + a.bins2) TY[tid - 128] = a.wy[(size_t)head * a.bins2 + tid - 128] * f;
-            cur_head = head;
-        }
+        auto fill_tables = [&]() __attribute__((always_inline)) {
+            if (BIAS && head != cur_head) {            // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
+                float* T1 = reinterpret_cast<float*>(smem + OFF_T1);
+                float* TX = reinterpret_cast<float*>(smem + OFF_TX);
+                float* TY = reinterpret_cast<float*>(smem + OFF_TY);
+                const float f = a.inv_sqrt_d * sc2;
+                if (tid < a.bins1) T1[tid] = a.w1[(size_t)head * a.bins1 + tid] * f;
+                if (tid == a.bins1) T1[tid] = kNegBig;
+                if (tid >= 64 && tid < 64 + a.bins2) TX[tid - 64] = a.wx[(size_t)head * a.bins2 + tid - 64] * f;
+                if (tid >= 128 && tid < 128 + a.bins2) TY[tid - 128] = a.wy[(size_t)head * a.bins2 + tid - 128] * f;
+                cur_head = head;
+            }
+        };
+        fill_tables();
 
         const int slab = BIAS ? __builtin_amdgcn_readfirstlane(a.doc_orig[doc]) : 0;      // fetched before the counted regime starts
         const int qb = (q0 >> 5) + wave;               // this wave's 32-query block of the document
@@ -279,11 +274,12 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         const int qrow = qoff + (qi < len ? qi : len - 1);
         // Q fragments (B operand of S^T = K Q^T): k-step s, element j <-> d = 16 s + 8 hh + j; split group s of the head
         f16x8 qh[4], ql[4];
-        {
+        auto load_q = [&]() __attribute__((always_inline)) {
             const char* qp = reinterpret_cast<const char*>(a.qkv) + (size_t)qrow * row_bytes + (size_t)head * 256 + 16 * hh;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // table fill / previous item's stores: done before the counted regime starts
-            // asm loads: from here to the end of the item only hand-counted vector memory operations are in flight.  They are older than
-            // the first tiles' DMA pieces issued below, so the counted wait at the top of tile 0 covers them; no wait of their own.
+            // asm loads: from here to the end of the item only hand-counted vector memory operations are issued.  Operations that are still
+            // in flight from before (the previous item's context stores, the table loads, the queue atomic) are OLDER and the counter
+            // retires in issue order, so every counted wait below still covers what it names (it can only wait a little longer).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // start clean (not required for correctness: older operations retire first)
             asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
                          "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
                          "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
@@ -291,7 +287,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                          : "=&v"(qh[0]), "=&v"(ql[0]), "=&v"(qh[1]), "=&v"(ql[1]), "=&v"(qh[2]), "=&v"(ql[2]), "=&v"(qh[3]), "=&v"(ql[3])
                          : "v"(qp)
                          : "memory");
-        }
+        };
+        load_q();
 
         // ---- LDS-DMA of the K / V tiles.  kv_wave: first row of THIS WAVE's four pieces of tile 0 (K or V section of the head) ----
         const size_t sect = (size_t)(img + 1) * (size_t)a.H * 4 + (size_t)head * 256;
@@ -369,11 +366,6 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
             unsigned vb = vs;
             asm volatile("" : "+v"(vb));
-            unsigned va[8];                               // XP & 4: vb ^ (64 dh + 128 plane + 32 x), index 4 dh + 2 plane + x
-            if (XP & 4) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) va[c] = vb ^ (64u * (unsigned)(c >> 2) + 128u * (unsigned)((c >> 1) & 1) + 32u * (unsigned)(c & 1));
-            }
             // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
             // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
 #pragma unroll
@@ -400,8 +392,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 for (int dh = 0; dh < 2; ++dh) {
                     // rows 16 ks + row0 (+ 8), chunk (dch0 + 4 dh) + 8 plane: address = (vb ^ (64 dh + 128 plane + 32 x)) + 2048 x + 4096 ks
                     auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
-                        const unsigned ad = (XP & 4) ? va[4 * ((xorc >> 6) & 1) + 2 * ((xorc >> 7) & 1) + ((xorc >> 5) & 1)] : (vb ^ xorc);
-                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)(ad + addc));
+                        return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)((vb ^ xorc) + addc));
                     };
                     const h4 vh0 = trd(64u * dh, 4096u * ks);
                     const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
@@ -442,235 +433,11 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                          : "memory");
         };
 
-        if constexpr ((XP & 8) != 0) {
-        // =================================================================================================================
-        // XP & 8: SOFTWARE-PIPELINED tiles.  The matrix pipe is hidden behind the vector / LDS instruction stream (header), and a wave's
-        // dependent MFMA chains (12 for Q K^T, 2 x 6 for P V) leave ~24 issue cycles between consecutive MFMAs that only THIS wave's
-        // independent instructions can use.  So one iteration pairs, in one basic block each,
-        //     Q K^T of tile kt + 1  (matrix)  with  exp / row sum / f16 split of tile kt  (vector), and
-        //     P V of tile kt        (matrix)  with  the bias lookups + adds of tile kt + 1 (vector + LDS);
-        // the scores of tile kt + 1 are complete when the iteration ends.  The rare "move the reference maximum" branch sits in front of
-        // the first block.  Ring discipline: tile kt + 1 must have landed at the TOP of iteration kt (one iteration after its DMA was
-        // issued), tile kt + 2 goes into the slot of tile kt - 1 behind the iteration's barrier.  Barriers: one in the prologue and one
-        // per iteration that has a next tile, the same count as the plain loop; idle waves follow the same schedule.
-        // =================================================================================================================
-        issue_any(0, 0u);
-        if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
-        STAMP(6, tprev)
-        if (!wave_active) {
-            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
-            unsigned sbp = 2u * STAGE_BYTES;             // slot of tile kt - 1 = slot of tile kt + 2
-            for (int kt = 0; kt + 1 < n_kt; ++kt) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt + 1 (nothing younger is in flight)
-                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
-                if (kt + 2 < n_kt) issue_any(kt + 2, sbp);
-                sbp = sbp == 2u * STAGE_BYTES ? 0u : sbp + (unsigned)STAGE_BYTES;
-            }
-            continue;
-        }
-        if (want_idx) issue_idx(0);
-        // Q K^T of one tile out of the slot at `sbk`, from a zero accumulator; VAR says which DMA pieces ride between the MFMAs
-        auto qk_chain = [&](auto var_tag, f32x16& s, const unsigned sbk, const int kt2, const unsigned sb2) __attribute__((always_inline)) {
-            constexpr int VAR = decltype(var_tag)::value;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
-            const unsigned kb = kbase + sbk;
-            f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
-#pragma unroll
-            for (int stp = 0; stp < 4; ++stp) {
-                f16x8 khn = kh, kln = kl;
-                if (stp < 3) {
-                    khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
-                    kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
-                }
-                if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);
-                else asm volatile("" :: "v"(kl), "v"(kh));
-                if (VAR == V_HOT) issue_full(kt2, sb2, stp);
-                if (VAR == V_TAIL) issue_tail(kt2, sb2, stp);
-                if (!(MODE == 2 && (dbg & 128))) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
-                }
-                kh = khn;
-                kl = kln;
-            }
-        };
-        auto bias_add = [&](f32x16& s) __attribute__((always_inline)) {
-            const u32x4 iw[4] = {iw0, iw1, iw2, iw3};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const unsigned v = iw[p][t];
-                    const float b1 = lds_load<float>((v & 0x3ffu) + (unsigned)OFF_T1);
-                    const float bx = lds_load<float>(((v >> 10) & 0x3ffu) + (unsigned)OFF_TX);
-                    const float by = lds_load<float>((v >> 20) + (unsigned)OFF_TY);
-                    s[4 * p + t] += b1 + (bx + by);          // rel_pos + (rel_pos_x + rel_pos_y), HF:268, 455; masked: -1e30
-                }
-            }
-        };
-        auto tail_mask = [&](f32x16& s, const int kt) __attribute__((always_inline)) {      // image-only model: keys past the document
-            const int k0 = kt * KT;
-            if (k0 + KT > len) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[e] = (k0 + (e & 3) + 8 * (e >> 2) + 4 * hh >= len) ? kNegBig : s[e];
-            }
-        };
-        // ---- tile 0's scores ----
-        if (want_idx) {
-            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            if (n_kt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        STAMP(0, tprev)
-        if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
-        STAMP(7, tprev)
-        f32x16 s_cur;
-        qk_chain(std::integral_constant<int, V_LAST>{}, s_cur, 0u, 0, 0u);
-        if (want_idx) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            bias_add(s_cur);
-            if (n_kt > 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                issue_idx(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (!BIAS) tail_mask(s_cur, 0);
-        STAMP(3, tprev)
-
-        unsigned sb = 0u;                                    // slot of tile kt
-        auto iter = [&](auto var_tag, const int kt) __attribute__((always_inline)) {
-            constexpr int VAR = decltype(var_tag)::value;
-            constexpr bool more1 = VAR != V_LAST, issue2 = VAR == V_HOT || VAR == V_TAIL;
-            const unsigned sb1 = sb == 2u * STAGE_BYTES ? 0u : sb + (unsigned)STAGE_BYTES;      // slot of tile kt + 1
-            const unsigned sb2 = sb == 0u ? 2u * STAGE_BYTES : sb - (unsigned)STAGE_BYTES;      // slot of tile kt - 1 = of tile kt + 2
-            if (more1) {
-                // tile kt + 1 has landed: only this wave's index loads of tile kt + 1 (issued after its pieces) may still be in flight
-                if (want_idx) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                STAMP(0, tprev)
-                if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
-                STAMP(7, tprev)
-            }
-            // reference maximum of tile kt (lazy: moves only when exceeded by 2^5), before the paired blocks
-            const bool do_sm = !(MODE == 2 && (dbg & 2));
-            if (do_sm) {
-                float tmax = fmaxf(fmaxf(s_cur[0], s_cur[1]), s_cur[2]);
-#pragma unroll
-                for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, s_cur[e]), s_cur[e + 1]);
-                tmax = fmaxf(tmax, s_cur[15]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                if (__any(tmax > st.mref + lazy)) {
-                    const float mnew = fmaxf(st.mref, tmax);
-                    const float alpha = __builtin_amdgcn_exp2f((st.mref - mnew) * cexp);
-                    st.mref = mnew;
-                    st.l *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { st.o0[e] *= alpha; st.o1[e] *= alpha; }
-                }
-            }
-            // ---- block 1: Q K^T of tile kt + 1 (matrix)  ||  exp, row sum, f16 split of tile kt (vector) ----
-            f32x16 s_nxt;
-            if (more1) qk_chain(var_tag, s_nxt, sb1, kt + 2, sb2);
-            unsigned hw[8], lw[8];
-            if (do_sm) {
-                const float negm = kPShift - st.mref * cexp;
-                float psum = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s_cur[e] = __builtin_amdgcn_exp2f(fmaf(s_cur[e], cexp, negm));      // 2^10 p, p relative to the reference maximum
-                    psum += s_cur[e];
-                }
-                st.l += psum;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {      // split of P: hi = f16(x), lo = f16(x - hi) by v_fma_mixlo / mixhi_f16
-                const float x0 = s_cur[2 * j], x1 = s_cur[2 * j + 1];
-                const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
-                const unsigned hb = __builtin_bit_cast(unsigned, h);
-                unsigned lb;
-                asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-                    "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                    : "=&v"(lb)
-                    : "v"(x0), "v"(x1), "v"(hb));
-                hw[j] = hb;
-                lw[j] = lb;
-            }
-            STAMP(3, tprev)
-            // ---- block 2: P V of tile kt (matrix)  ||  bias of tile kt + 1 (vector + LDS) ----
-            if (more1 && want_idx) {
-                // the index words of tile kt + 1 are back when all but the pieces of tile kt + 2 issued above are (they are older)
-                if (issue2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (!(MODE == 2 && (dbg & 8))) {
-                const unsigned vb = vbase + sb;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const u32x4 hq = {hw[4 * ks], hw[4 * ks + 1], hw[4 * ks + 2], hw[4 * ks + 3]};
-                    const u32x4 lq = {lw[4 * ks], lw[4 * ks + 1], lw[4 * ks + 2], lw[4 * ks + 3]};
-                    const f16x8 ph8 = __builtin_bit_cast(f16x8, hq), pl8 = __builtin_bit_cast(f16x8, lq);
-#pragma unroll
-                    for (int dh = 0; dh < 2; ++dh) {
-                        auto trd = [&](unsigned xorc, unsigned addc) __attribute__((always_inline)) {
-                            return __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(size_t)((vb ^ xorc) + addc));
-                        };
-                        const h4 vh0 = trd(64u * dh, 4096u * ks);
-                        const h4 vh1 = trd(64u * dh + 32u, 4096u * ks + 2048u);
-                        const h4 vl0 = trd(64u * dh + 128u, 4096u * ks);
-                        const h4 vl1 = trd(64u * dh + 128u + 32u, 4096u * ks + 2048u);
-                        f16x8 vh, vl;
-                        const f16x4 a0 = __builtin_bit_cast(f16x4, vh0), a1 = __builtin_bit_cast(f16x4, vh1);
-                        const f16x4 b0 = __builtin_bit_cast(f16x4, vl0), b1 = __builtin_bit_cast(f16x4, vl1);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
-                        if (dh == 0) {
-                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
-                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
-                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
-                        } else {
-                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
-                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
-                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
-                        }
-                    }
-                }
-            } else {
-                asm volatile("" :: "v"(hw[0]), "v"(lw[3]), "v"(hw[5]), "v"(lw[7]));
-            }
-            if (more1) {
-                if (want_idx) {
-                    bias_add(s_nxt);
-                    if (issue2) {                 // the registers are free: the words of tile kt + 2
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_idx(kt + 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (!BIAS) tail_mask(s_nxt, kt + 1);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s_cur[e] = s_nxt[e];
-            }
-            STAMP(4, tprev)
-            sb = sb1;
-        };
-        {
-            int kt = 0;
-            for (; kt + 2 < n_full; ++kt) iter(std::integral_constant<int, V_HOT>{}, kt);           // tile kt + 2 is a whole tile
-            if (kt + 2 < n_kt) { iter(std::integral_constant<int, V_TAIL>{}, kt); ++kt; }            // ... is the partial last tile
-            if (kt + 1 < n_kt) { iter(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
-            iter(std::integral_constant<int, V_LAST>{}, kt);
-        }
-        } else {
         // ---- prologue: tiles 0 and 1 into slots 0 and 1, the index words of tile 0 ----
         issue_any(0, 0u);
         if ((XP & 2) && wave_active && want_idx) issue_idx(0);      // bias first: the index words of a tile are older than the DMA of the tile after it
         if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the table stores have left this wave before it reaches tile 0's barrier
         STAMP(6, tprev)
 
         if (!wave_active) {
@@ -785,23 +552,36 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (kt + 1 < n_kt) { tile(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
             tile(std::integral_constant<int, V_LAST>{}, kt);
         }
-        }      // plain / pipelined loop
 
         {
             const float l_tot = st.l + __shfl_xor(st.l, 32, 64);   // the two lane halves hold disjoint keys
             const float inv = 1.0f / (l_tot * a.qkv_scale);        // the 2^10 of the probabilities is in l as well
-            if (qi < len) {
-                char* row_split = reinterpret_cast<char*>(a.ctx) + (size_t)(off + qi) * a.ldc * 4;
+            // context row of this lane's query as split planes.  The two lane halves of a query hold neighbouring 4-column groups (hh = 0:
+            // columns 8 q4 .. + 3, hh = 1: + 4 .. + 7), i.e. adjacent 8-byte pieces of the hi plane and of the lo plane.  One
+            // v_permlane32_swap per dword gives the lower half both hi pieces and the upper half both lo pieces: 8 stores of 16 bytes per
+            // lane instead of 16 of 8 (the epilogue was store-issue bound: guide T21).
+            char* row_split = reinterpret_cast<char*>(a.ctx) + (size_t)(off + (qi < len ? qi : len - 1)) * a.ldc * 4 + 32 * hh;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
-                    f32x4 w0, w1;
+            for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { w0[c] = st.o0[4 * q4 + c] * inv; w1[c] = st.o1[4 * q4 + c] * inv; }
-                    store_split4(row_split, head * D + 4 * hh + 8 * q4, w0, a.ctx_scale, amax);
-                    store_split4(row_split, head * D + 4 * hh + 8 * q4 + 32, w1, a.ctx_scale, amax);
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 w;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = (half ? st.o1[4 * q4 + c] : st.o0[4 * q4 + c]) * inv;
+                    f16x4 hi, lo;
+                    split_f16x4(w, a.ctx_scale, hi, lo, amax);
+                    const u32x2 hx = __builtin_bit_cast(u32x2, hi), lx = __builtin_bit_cast(u32x2, lo);
+                    // lanes 32-63 of the first operand swap with lanes 0-31 of the second: lower half = [own hi | partner's hi],
+                    // upper half = [partner's lo | own lo]
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(hx[0], lx[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(hx[1], lx[1], false, false);
+                    const u32x4 piece = {(unsigned)s0[0], (unsigned)s1[0], (unsigned)s0[1], (unsigned)s1[1]};
+                    const int col = head * D + 8 * q4 + 32 * half;           // first of the pair's 8 columns
+                    if (qi < len) *reinterpret_cast<u32x4*>(row_split + (col >> 4) * 64 + (col & 15) * 2) = piece;
                 }
             }
         }
+        STAMP(5, tprev)                                                       // normalisation, split conversion, context stores
     }
     if (a.ctx_split && MODE != 2) split_flag_overflow(amax, a.err_flag);      // the timing variants compute garbage by design
     if (DIAG && stamps && lane == 0) {
@@ -862,12 +642,8 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
     if (a.pair_idx && xp != kXP) {
         switch (xp) {
             case 0: launch_idx<true, 0>(a, max_docs, num_cus, stamps, dbg, s); return;
-            case 1: launch_idx<true, 1>(a, max_docs, num_cus, stamps, dbg, s); return;
             case 2: launch_idx<true, 2>(a, max_docs, num_cus, stamps, dbg, s); return;
-            case 4: launch_idx<true, 4>(a, max_docs, num_cus, stamps, dbg, s); return;
-            case 6: launch_idx<true, 6>(a, max_docs, num_cus, stamps, dbg, s); return;
-            case 7: launch_idx<true, 7>(a, max_docs, num_cus, stamps, dbg, s); return;
-            case 8: launch_idx<true, 8>(a, max_docs, num_cus, stamps, dbg, s); return;
+
             default: break;
         }
     }

@@ -1005,8 +1005,9 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             fill_idx(at);
             return at;
         };
-        auto beit_run_attn = [&](const AttnArgs& at) {
-            if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s);
+        auto beit_run_attn = [&](const AttnArgs& at) {      // no relative-position bias: at.pair_idx is null, the kernel masks the last key tile's tail
+            if (sp && mmee::attention_idx_supports(at)) mmee::launch_attention_idx(at, B, cus, s);
+            else if (sp) launch_attention_pair(at, B, cus, c.max_rel_pos, c.max_rel_2d_pos, (flags & MMEE_FLAG_DENSE_ROWS) ? 1 : 0, s);
             else launch_attention_f32(at, B, cus, s);
         };
         auto beit_rest = [&](const int* x_rows, const int* qkv_off) {

@@ -11,6 +11,7 @@ for v in "$@"; do
     envs=""
     for kv in $v; do
         case $kv in
+            WORDS=*|B=*) envs="$envs $kv";;
             LIB=*) envs="$envs MMEE_LIB=$PWD/tools/bin/libmmee_hip_diag_${kv#LIB=}.so";;      # an earlier build kept under tools/bin (same-box A/B)
             *) envs="$envs MMEE_ATTN_${kv}";;
         esac

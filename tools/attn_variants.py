@@ -13,7 +13,9 @@ B = int(os.environ.get("B", "256"))
 W = pkg.synth.make_weights(cfg, seed=1234, head_gain=6.0)
 eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=512)
 eng.load_weights(W)
-d = pkg.synth.make_documents(cfg, B, seed=5, text_len=512)
+# WORDS=<n>: every document has exactly n words (n + 2 + 197 rows): how the rate depends on the length of an item's key loop
+_w = os.environ.get("WORDS")
+d = pkg.synth.make_documents(cfg, B, seed=5, text_len=512, **({"min_words": int(_w), "max_words": int(_w)} if _w else {}))
 args = (d["input_ids"], d["attention_mask"], d["bbox"], d["pixel_values"])
 for _ in range(2):
     eng.forward(*args, dump_all=True)
@@ -23,5 +25,5 @@ eng.forward(*args, dump_all=True)
 p = eng.profile_read()
 fl = eng.flops()
 ms = p["attention"]["ms"]
-sw = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MMEE_ATTN_"))
+sw = " ".join(f"{k[10:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MMEE_ATTN_")) + (f" WORDS={_w}" if _w else "")
 print(f"[{sw}] attention {ms:.2f} ms / forward  ({fl['attention'] / ms / 1e9:.1f} TFLOP/s algorithmic)  B={B}")
