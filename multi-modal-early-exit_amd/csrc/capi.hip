@@ -1111,7 +1111,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             GemmArgs g{};
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = x_rows;
             g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
-            g.alpha = w.ao_inv / mmee::kSplitScaleCtx;
+            g.alpha = w.ao_inv / mmee::kSplitScaleCtx; g.role_tag = 2;
             g.m_ptr = rp; g.N = H; g.K = H; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GAO, s); run_gemm(g, EPI_RESID); }
             // split mode: the LayerNorm output exists only as split planes (22 bits); its readers (next GEMM, residual adds, exit heads) take it from there
@@ -1123,7 +1123,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             g = GemmArgs{};
             g.A = h->H1; g.lda = I; g.W = sp ? w.f2_s : w.f2_w; g.bias = w.f2_b; g.C = h->X; g.ldc = H; g.resid = sp ? h->Ys : h->Y; g.ldr = H;
             g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
-            g.alpha = w.f2_inv / mmee::kSplitScaleH1;
+            g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.role_tag = 3;
             g.m_ptr = rp; g.N = H; g.K = I; g.scale = 1.f; g.tile_counter = next_head(); g.prio_mode = 1; g.err_flag = h->err_flag;
             { ProfScope ps(h, P_GDOWN, s); run_gemm(g, EPI_RESID); }
             { ProfScope ps(h, P_LN, s); launch_ln_rows(h->X, sp ? nullptr : h->X, nullptr, rp, max_rows, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, sp ? h->Xs : nullptr, mmee::kSplitScaleX, h->err_flag); }

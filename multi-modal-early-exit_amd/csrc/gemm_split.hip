@@ -304,8 +304,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 const int gl = j / per_group, r = j - gl * per_group;
                 const int grp = q + 8 * gl;
                 if (grp < n_groups) {
-                    tn = r / GM;
-                    tm = grp * GM + (r - tn * GM);
+                    if (g.tile_order == 1) {
+                        const int mi = r / tiles_n;
+                        tn = r - mi * tiles_n;
+                        tm = grp * GM + mi;
+                    } else {
+                        tn = r / GM;
+                        tm = grp * GM + (r - tn * GM);
+                    }
                     if (tm < tiles_m) return true;
                     continue;
                 }
@@ -389,6 +395,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
         }
 
         int buf = buf0, bufn = (buf0 + NST - 1) % NST;     // slots of stage kt and of stage kt + NST - 1
+        // (measured, round 3: forcing the k-loop's first instruction onto a 32 / 64 / 256-byte boundary with .p2align changes nothing: 6564-6593
+        // docs/s for all four builds on one box, tools/lib_ab.sh)
         for (int kt = 0; kt < nk; ++kt) {
             // my pieces of stage kt have landed (NST == 3: the pieces of stage kt + 1 may still be in flight), then the
             // barrier: everyone's have, and everyone has left stage kt - 1, whose slot the next issue overwrites
@@ -517,8 +525,16 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
 // CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283), CfgP for the CLS-probe
 // GEMMs.  The release library holds exactly these; the other configurations (MMEE_SPLIT_CFG=1 / 2 for CfgA / CfgB) and the timing
 // diagnostics (GemmArgs::dbg_noload, wrong results) are compiled into the diagnostic library only (make diag, -DMMEE_DIAG).
-void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipStream_t s) {
+void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hipStream_t s) {
+    GemmArgs a = a_in;
+    // queue order: with N <= 768 (attention output, FFN down: three N-tiles) the whole W operand stays in an XCD's L2, so the A panel is
+    // what consecutive tickets should share (N fastest): FFN down 402 -> 414 TFLOP/s, attention output unchanged (tools/gemm_split_shapes.py);
+    // wider GEMMs keep eight M-tiles per W tile back to back (QKV, FFN up: unchanged to -0.6 % with N fastest)
+    a.tile_order = a.N <= 768 ? 1 : 0;
 #ifdef MMEE_DIAG
+    static const int order_env = diag_env_int("MMEE_GEMM_ORDER", -1);      // A/B of the queue order: 0 / 1 for every GEMM, 2 = N fastest where N <= 768
+    if (order_env == 0 || order_env == 1) a.tile_order = order_env;
+    else if (order_env == 2) a.tile_order = a.N <= 768 ? 1 : 0;
     static const int forced = diag_env_int("MMEE_SPLIT_CFG", 0);      // 1 = CfgA, 2 = CfgB, 0 / 3 = CfgC
     const bool use_a = forced == 1;
     if (a.dbg_noload && (forced == 0 || forced == 3)) {      // timing diagnostics of the default configuration (tools/gemm_split_shapes.py)
@@ -572,7 +588,11 @@ void launch_gemm_split(const GemmArgs& a, int epi, int max_m, int num_cus, hipSt
     switch (epi) {
         case EPI_BIAS: launch_split_one<CfgC, EPI_BIAS, false>(a, max_m, num_cus, s); break;
         case EPI_GELU: launch_split_one<CfgC, EPI_GELU, false>(a, max_m, num_cus, s); break;
-        case EPI_RESID: launch_split_one<CfgC, EPI_RESID, false>(a, max_m, num_cus, s); break;
+        case EPI_RESID:
+            if (a.role_tag == 2) launch_split_one<CfgC, EPI_RESID, false, false, 2>(a, max_m, num_cus, s);
+            else if (a.role_tag == 3) launch_split_one<CfgC, EPI_RESID, false, false, 3>(a, max_m, num_cus, s);
+            else launch_split_one<CfgC, EPI_RESID, false>(a, max_m, num_cus, s);
+            break;
         default: launch_split_one<CfgC, EPI_TANH, false>(a, max_m, num_cus, s); break;
     }
 }

@@ -237,6 +237,10 @@ struct GemmArgs {
     float out_scale;
     int use_dma;                     // 0 = default (LDS-DMA kernel unless MMEE_GEMM_DMA=0), 1 = LDS-DMA kernel, 2 = register-staged kernel
     int probe;                       // split kernel: 1 = the CLS-probe instantiation (same code, its own kernel name for the profiler)
+    int role_tag;                    // split kernel, residual epilogue: 2 = attention output, 3 = FFN down (same code, own kernel names: the two
+                                     // share every template argument, and a profiler could not tell them apart)
+    int tile_order;                  // work-queue order inside a group of 8 M-tiles: 0 = M fastest (eight tiles share a W tile back to back),
+                                     // 1 = N fastest (the N-tiles of one M-panel follow each other: they share the A panel)
     int prio_mode;                   // 0 none, 1 raise the priority of odd hardware wave slots, 2 of the second half of the grid
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
     int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
