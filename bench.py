@@ -267,21 +267,23 @@ def sweep_workload(a):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     kms = e0.elapsed_time(e1) / a.steps
-    # algorithmic work: one compare per (vector, document, exit) until the first hit -- bounded by V * N * E1 compares; algorithmic
-    # bytes: the (conf f64 + correct u8) table once, the thresholds once, 16 + 4 E1 bytes of results per vector
-    alg_bytes = E1 * N * 9.0 + V * E1 * 8.0 + V * (16.0 + 4.0 * E1)
-    cmp_per_s = V * N * E1 / (kms * 1e-3)
-    # VALU bound: one f64 compare + select per (vector, document, exit) in the worst case; 256 CUs x 4 SIMDs x 16 f64 lanes / clk
-    valu_peak = N_SIMD * 16 * PEAK_CLOCK_GHZ * 1e9
+    # algorithmic work of the main kernel (exit_ops.hip, sweep_main_kernel): per (vector, document) 2 E1 + 4 integer vector operations
+    # (compare + select per exit, payload decode + two adds); algorithmic bytes: the rank table once per 256 vectors from
+    # L2, the thresholds once, 16 bytes of results per vector
+    ops_per_pair = 2 * E1 + 4
+    alg_bytes = E1 * N * 9.0 + V * E1 * 8.0 + V * 16.0
+    cmp_per_s = V * N * ops_per_pair / (kms * 1e-3)
+    # VALU bound: 1024 SIMDs x 32 lanes per clock (a wave64 instruction issues in 2 cycles, MI355X_MICROARCH.md cycle constants)
+    valu_peak = N_SIMD * 32 * PEAK_CLOCK_GHZ * 1e9
     line = {"metric": "threshold_vectors_per_sec", "value": V / dt, "unit": "vectors/s", "n_gpus": 1, "rccl_ranks": 0, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 compares",
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 ranks (exact order transform of the f64 table)",
             "data": "synthetic",
             "config": {"workload": f"SURVEY 8f N3: threshold sweep of EE/large_scale.py:46-84 on the device, {E1} exits x {N} documents x {V} "
                                    "threshold vectors (reference: num_mixtures = 1 500 000, EE/large_scale.py:179-180)",
                        "exits": E1, "docs": N, "vectors": V},
-            "roofline": {"bound": "valu (f64 compare per (vector, document, exit)); the table is read once per workgroup from L2",
-                         "kernel": "threshold_sweep_kernel", "achieved": cmp_per_s / 1e12, "peak": valu_peak / 1e12,
-                         "unit": "T compare/s", "frac": cmp_per_s / valu_peak, "avg_launch_ms": kms,
+            "roofline": {"bound": "valu (integer compare + select on ranks; the rank table is read once per 256 vectors from L2)",
+                         "kernel": "sweep_rank_kernel + sweep_thr_kernel + sweep_main_kernel<7>", "achieved": cmp_per_s / 1e12, "peak": valu_peak / 1e12,
+                         "unit": "T lane-op/s", "frac": cmp_per_s / valu_peak, "avg_launch_ms": kms, "lane_ops_per_vector_document": ops_per_pair,
                          "algorithmic_hbm_bytes_per_launch": alg_bytes, "hbm_GBps_algorithmic": alg_bytes / (kms * 1e-3) / 1e9,
                          "traffic": None}}
     # numpy baseline on a bounded sample of the vectors: the reference's own expression (EE/large_scale.py:46-84)

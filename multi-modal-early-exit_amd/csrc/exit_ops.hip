@@ -312,8 +312,155 @@ __global__ __launch_bounds__(256) void threshold_sweep_kernel(const double* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The sweep at the reference's scale (EE/large_scale.py:46-84 with num_mixtures = 1 500 000 threshold vectors, :179-180).  The kernel above
+// re-reads the whole (E1, N) float64 table for every vector (2.2 MB x 1.5 M = 3.4 TB of cache traffic) and compares doubles.  Only the
+// ORDER of conf[e][n] and thr[v][e] matters, so the comparison is done on integer ranks instead:
+//     p[e][n] = #{m : conf[e][m] < conf[e][n]},   t[v][e] = #{m : conf[e][m] < thr[v][e]}      =>      conf[e][n] >= thr[v][e]  <=>  p[e][n] >= t[v][e]
+// (>=: every element below thr is below conf, so t <= p; <: conf itself and everything below it is below thr, so t >= p + 1).  Exact for any
+// doubles, ties and duplicates included (NaN confidences do not occur: they are softmax maxima).
+//   1. sweep_rank_kernel   p by counting (N^2 / exit, 1.1e10 double compares at 7 x 40 000: ~1 ms) and, with the tie index from the same pass,
+//                          the sorted confidences of every exit;
+//   2. sweep_thr_kernel    t by binary search in the sorted row;
+//   3. sweep_main_kernel   one THREAD per threshold vector (its E1 ranks in registers, its two sums in registers: no reduction across
+//                          lanes), the documents streamed through LDS as records  rec[e] = p << 8 | correct << 6 | e  that every lane reads
+//                          at the same address (broadcast).  exit = first e with rec[e] >= t[e] << 8, else 0 (numpy argmax of an all-False
+//                          column): r = rec[0]; for e = E1 - 1 .. 0: r = rec[e] >= T[e] ? rec[e] : r  -- two vector instructions per exit --
+//                          and the payload bits of r give (correct, exit).  Integer work per (vector, document): 2 E1 + 4 instructions.
+// The table is read once per 256 vectors from L2 (1.3 MB x V / 256).  Needs N < 2^24 and E1 <= 64; the histogram output stays on the kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_rank_kernel(const double* __restrict__ conf, const unsigned char* __restrict__ correct, int E1, int E1P,
+                                                         int N, unsigned* __restrict__ rec, double* __restrict__ sorted) {
+    __shared__ double tile[2048];
+    const int e = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const double* row = conf + (size_t)e * N;
+    const double c = n < N ? row[n] : 0.0;
+    unsigned lt = 0, eq_before = 0;
+    for (int m0 = 0; m0 < N; m0 += 2048) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2048; i += 256) tile[i] = m0 + i < N ? row[m0 + i] : 0.0;
+        __syncthreads();
+        const int cnt = N - m0 < 2048 ? N - m0 : 2048;
+        for (int i = 0; i < cnt; ++i) {
+            const double x = tile[i];
+            lt += x < c ? 1u : 0u;
+            eq_before += (x == c && m0 + i < n) ? 1u : 0u;
+        }
+    }
+    if (n < N) {
+        rec[(size_t)n * E1P + e] = (lt << 8) | ((unsigned)(correct[(size_t)e * N + n] ? 1u : 0u) << 6) | (unsigned)e;
+        sorted[(size_t)e * N + lt + eq_before] = c;                  // equal values take consecutive places in document order
+    }
+}
+
+__global__ __launch_bounds__(256) void sweep_thr_kernel(const double* __restrict__ sorted, const double* __restrict__ thr, int E1, int N, long long VE,
+                                                        unsigned* __restrict__ T) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < VE; i += (long long)gridDim.x * 256) {
+        const int e = (int)(i % E1);
+        const double t = thr[i];
+        const double* row = sorted + (size_t)e * N;
+        int lo = 0, hi = N;                                          // first index with row[idx] >= t  =  number of confidences below t
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (row[mid] < t) lo = mid + 1;
+            else hi = mid;
+        }
+        T[i] = t != t ? 0xffffffffu : (unsigned)lo << 8;             // conf >= NaN is false for every document (numpy): a word no record reaches
+    }
+}
+
+template <int E1C>      // E1C > 0: compile-time exit count (unrolled, ranks in registers); 0: run-time E1 (ranks re-read from the vector's row)
+__global__ __launch_bounds__(256, 2) void sweep_main_kernel(const unsigned* __restrict__ rec, const unsigned* __restrict__ T, int E1, int E1P, int N,
+                                                            int V, double* __restrict__ acc, double* __restrict__ mean_exit) {
+    extern __shared__ unsigned s_rec[];                              // CHUNK documents x E1P words
+    const int chunk = (64 * 1024) / (4 * E1P);
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int vv = v < V ? v : V - 1;
+    unsigned tq[E1C > 0 ? E1C : 1];
+    if (E1C > 0) {
+#pragma unroll
+        for (int e = 0; e < E1C; ++e) tq[e] = T[(size_t)vv * E1 + e];
+    }
+    unsigned n_correct = 0, sum_exit = 0;
+    for (int n0 = 0; n0 < N; n0 += chunk) {
+        const int cnt = N - n0 < chunk ? N - n0 : chunk;
+        __syncthreads();
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(rec + (size_t)n0 * E1P);
+            uint4* dst = reinterpret_cast<uint4*>(s_rec);
+            const int n16 = cnt * E1P / 4;
+            for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        if (E1C > 0) {
+#pragma unroll 4
+            for (int i = 0; i < cnt; ++i) {
+                const unsigned* d = s_rec + i * E1P;                 // the same address in every lane: a broadcast read
+                const unsigned d0 = d[0];
+                unsigned r = d0;                                     // no exit fires: exit 0
+#pragma unroll
+                for (int e = E1C - 1; e >= 1; --e) {
+                    const unsigned x = d[e];
+                    r = x >= tq[e] ? x : r;
+                }
+                r = d0 >= tq[0] ? d0 : r;                            // exit 0 fires: it is the first
+                n_correct += (r >> 6) & 1u;
+                sum_exit += r & 63u;
+            }
+        } else {
+            for (int i = 0; i < cnt; ++i) {
+                const unsigned* d = s_rec + i * E1P;
+                const unsigned d0 = d[0];
+                unsigned r = d0;
+                for (int e = E1 - 1; e >= 1; --e) {
+                    const unsigned x = d[e];
+                    r = x >= T[(size_t)vv * E1 + e] ? x : r;
+                }
+                r = d0 >= T[(size_t)vv * E1] ? d0 : r;
+                n_correct += (r >> 6) & 1u;
+                sum_exit += r & 63u;
+            }
+        }
+    }
+    if (v < V) {
+        acc[v] = (double)n_correct / (double)N;
+        mean_exit[v] = (double)sum_exit / (double)N;
+    }
+}
+
 void launch_threshold_sweep(const double* conf, const unsigned char* correct, int E1, int N, const double* thr, int V,
                             double* acc, double* mean_exit, int* hist, hipStream_t s) {
+    // ranks: the integer sweep (no histogram, N < 2^24, enough vectors to pay for the O(N^2) ranking pass)
+    const bool ranked = !hist && N < (1 << 24) && E1 <= 64 && (long long)V * 8 >= (long long)N;
+    if (ranked) {
+        const int E1P = (E1 + 3) & ~3;
+        unsigned *rec = nullptr, *T = nullptr;
+        double* sorted = nullptr;
+        if (hipMallocAsync((void**)&rec, (size_t)N * E1P * 4, s) == hipSuccess && hipMallocAsync((void**)&T, (size_t)V * E1 * 4, s) == hipSuccess &&
+            hipMallocAsync((void**)&sorted, (size_t)E1 * N * 8, s) == hipSuccess) {
+            (void)hipMemsetAsync(rec, 0, (size_t)N * E1P * 4, s);
+            hipLaunchKernelGGL(sweep_rank_kernel, dim3((N + 255) / 256, E1), dim3(256), 0, s, conf, correct, E1, E1P, N, rec, sorted);
+            const long long VE = (long long)V * E1;
+            int g2 = (int)((VE + 255) / 256 < 65536 ? (VE + 255) / 256 : 65536);
+            hipLaunchKernelGGL(sweep_thr_kernel, dim3(g2), dim3(256), 0, s, sorted, thr, E1, N, VE, T);
+            const int grid = (V + 255) / 256;
+            const size_t lds = 64 * 1024;
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_main_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_main_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr = true;
+            }
+            if (E1 == 7) hipLaunchKernelGGL((sweep_main_kernel<7>), dim3(grid), dim3(256), lds, s, rec, T, E1, E1P, N, V, acc, mean_exit);
+            else hipLaunchKernelGGL((sweep_main_kernel<0>), dim3(grid), dim3(256), lds, s, rec, T, E1, E1P, N, V, acc, mean_exit);
+            (void)hipFreeAsync(rec, s); (void)hipFreeAsync(T, s); (void)hipFreeAsync(sorted, s);
+            return;
+        }
+        (void)hipGetLastError();                                     // allocation failed: the direct kernel needs no workspace
+        if (rec) (void)hipFreeAsync(rec, s);
+        if (T) (void)hipFreeAsync(T, s);
+        if (sorted) (void)hipFreeAsync(sorted, s);
+    }
     int grid = V < 8192 ? V : 8192;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(threshold_sweep_kernel, dim3(grid), dim3(256), 0, s, conf, correct, E1, N, thr, V, acc, mean_exit, hist);

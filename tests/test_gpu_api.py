@@ -216,6 +216,37 @@ def test_threshold_sweep_matches_reference_semantics(pkg, oracle):
     assert (m2.cpu().numpy() == 0).all() and (h2.cpu().numpy()[:, 0] == N).all()
 
 
+@pytest.mark.parametrize("E1", [7, 5])
+def test_threshold_sweep_rank_kernels_are_bit_exact(pkg, oracle, E1):
+    """The sweep at scale runs on integer ranks (exit_ops.hip: rank / threshold-rank / main kernels, taken when there are many vectors and no
+    histogram is asked for).  Ties, duplicated confidences, thresholds that EQUAL a confidence, thresholds below / above every confidence and
+    the reference's zero last row (EE/large_scale.py:50-52) must give exactly the numbers of `(CSF >= thr[:, None]).argmax(0)`
+    (EE/large_scale.py:42-43, 87-96): accuracy and mean exit equal bit for bit, and equal to the direct kernel's."""
+    rng = np.random.default_rng(7 + E1)
+    N, V = 3000, 10000
+    conf = rng.uniform(0.05, 1.0, (E1, N))
+    conf[:, ::7] = np.round(conf[:, ::7], 2)                    # duplicates and ties
+    conf[2, :50] = conf[2, 50]                                  # a run of equal values
+    corr = (rng.random((E1, N)) < np.linspace(0.4, 0.9, E1)[:, None]).astype(np.uint8)
+    thr = rng.uniform(0.0, 1.1, (V, E1))
+    pick = rng.random((V, E1)) < 0.5                            # half of the thresholds sit exactly on a confidence of their exit
+    thr[pick] = conf[np.nonzero(pick)[1], rng.integers(0, N, int(pick.sum()))]
+    thr[:100] = 0.0                                             # everybody leaves at exit 0
+    thr[100:200] = 2.0                                          # nobody reaches any threshold: argmax of an all-False column = 0
+    thr[200:, -1] = 0.0                                         # the reference's last row
+    thr[300:400, 1] = np.nan                                    # a NaN threshold never fires (numpy >=)
+    acc_o, mex_o, hist_o = oracle.threshold_sweep(conf, corr, thr)
+    acc, mex, hist = pkg.sweep.threshold_sweep(conf, corr, thr)            # ranked path (V * 8 >= N, no histogram)
+    assert hist is None
+    np.testing.assert_array_equal(acc.cpu().numpy(), acc_o)
+    np.testing.assert_array_equal(mex.cpu().numpy(), mex_o)
+    acc2, mex2, hist2 = pkg.sweep.threshold_sweep(conf, corr, thr, want_hist=True)      # direct kernel
+    np.testing.assert_array_equal(hist2.cpu().numpy(), hist_o)
+    np.testing.assert_array_equal(acc2.cpu().numpy(), acc.cpu().numpy())
+    np.testing.assert_array_equal(mex2.cpu().numpy(), mex.cpu().numpy())
+    assert len(np.unique(mex_o)) > 100
+
+
 def test_large_shape_gate_temperature_matches_oracle(pkg, oracle):
     """BASELINE config-3 structure at reduced depth: LayoutLMv3-large widths (H=1024, 16 heads, coordinate 171 / shape
     170 -> unaligned spatial slices), exit at every layer, gate strategy (policy sees classifier(gate input)), per-exit
