@@ -699,11 +699,29 @@ def main(argv=None):
                 tried[bb_] = r_
                 if r_ > best["docs_per_sec"]:
                     best = {"B": bb_, "docs_per_sec": r_}
+        # the build's own C / OpenMP restatement, on two documents of the same batch
+        c_port = None
+        if not beit:
+            ocm = importlib.import_module("oracle.ee_oracle_c")
+            if ocm.available():
+                os.environ["OMP_NUM_THREADS"] = str(cores)
+                co = ocm.COracle(cfg, W)
+                nc = min(2, n)
+                t1 = time.perf_counter()
+                rc_ = [co.forward_all({k: v[i:i + 1] for k, v in docs.items()}, ee["exits"], strategy=strat)["logits_store"] for i in range(nc)]
+                c_dt = time.perf_counter() - t1
+                c_store = np.concatenate(rc_, axis=1)
+                if temps is not None:
+                    c_store = oracle.temperature_scale(c_store, temps)
+                c_port = {"value": nc / c_dt, "unit": "docs/s", "cores": cores, "docs": nc,
+                          "what": "oracle/ee_oracle_c.c: plain C + OpenMP float32 restatement (row-blocked dot products, no BLAS), B=1",
+                          "max_abs_dlogit_vs_torch_port": float(np.abs(c_store - store[:, :nc]).max())}
         line["cpu_baseline"] = {"value": n / cpu_dt, "unit": "docs/s", "cores": cores, "kind": "port",
                                 "sample": f"{n} documents of the same batch, B=1 per forward (reference default "
                                           f"eval_batch_size=1), full depth + all exits + simulated policy, "
                                           f"{'numpy' if beit else 'torch-CPU'} float32 restatement on {cores} host threads",
-                                "best_B": best, "docs_per_sec_by_batch_size": {str(k): round(v, 3) for k, v in tried.items()}}
+                                "best_B": best, "docs_per_sec_by_batch_size": {str(k): round(v, 3) for k, v in tried.items()},
+                                "c_openmp_port": c_port}
         g_ex = out.exit_layer.cpu().numpy()[:n]
         g_lg = out.logits.cpu().numpy()[:n]
         if g_ex.shape[0] == n:

@@ -57,6 +57,29 @@ def test_matrix_h256_forward_matches_reference(pkg, oracle, name):
         assert np.array_equal(ex, g[f"pol_exits{i}"])
 
 
+@pytest.mark.parametrize("name", list(TINY_CASES) + ["h256_gate"])
+def test_c_openmp_restatement_matches_reference(pkg, oracle, name):
+    """oracle/ee_oracle_c.c (the C / OpenMP restatement timed by bench.py's cpu_baseline beside torch-CPU) against the same golden vectors."""
+    import importlib
+    oc = importlib.import_module("oracle.ee_oracle_c")
+    if not oc.available():
+        pytest.skip("oracle/libee_oracle_c.so not built (make -C oracle)")
+    g = load_golden(name)
+    if name in TINY_CASES:
+        cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES[name])
+        W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+        docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    else:
+        cfg, ee, n_docs, T = matrix_config(pkg, name)
+        W = pkg.synth.make_weights(cfg, seed=MATRIX_SEEDS["seed_w"])
+        docs = pkg.synth.make_documents(cfg, n_docs, seed=MATRIX_SEEDS["seed_docs"], text_len=T, min_words=3)
+    ec = cfg.exit_config
+    out = oc.COracle(cfg, W).forward_all(docs, ec.exits, strategy=str(ec.encoder_layer_strategy), return_hidden_cls=True)
+    np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out["logits"], g["logits"], rtol=0, atol=1e-4)
+
+
 def test_tiny_policy_matches_reference(oracle):
     g = load_golden("tiny_ramp")
     for i in range(4):
