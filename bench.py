@@ -69,6 +69,11 @@ def parse(argv=None):
     ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
     ap.add_argument("--whole-layers", action="store_true", help="run exit layers whole before deciding (A/B switch of probe-first)")
     ap.add_argument("--probe-always", action="store_true", help="probe first at every exit layer (default: chosen per layer)")
+    ap.add_argument("--xprobe", dest="xprobe", action="store_true", default=True,
+                    help="probe-first layers take the CLS context in X space: no Q | K | V for documents that leave (default; "
+                         "MMEE_FLAG_XPROBE, built for LayoutLMv3-base shapes, other models run the K | V probe)")
+    ap.add_argument("--no-xprobe", dest="xprobe", action="store_false",
+                    help="probe with the layer's own K | V rows: an exit's row is then BIT-identical to the dump-all row (A/B switch)")
     ap.add_argument("--probe-layers", default=None,
                     help="comma list of 0-based layers to probe first ('' = none): pins the schedule instead of deriving it from the "
                          "warm-up (the rocprofv3 child passes get the parent's plan this way)")
@@ -395,10 +400,11 @@ def main(argv=None):
     if world > 1:                       # every rank uses rank 0's thresholds
         thr = pkg.dist.broadcast_array(thr, 0, device=dev)
 
-    def step(n=None):
+    def step(n=None, xprobe=None):
         sl = (lambda t: t if (t is None or n is None or n == B) else t[:n])
+        xp = a.xprobe if xprobe is None else xprobe
         return eng.forward(sl(d_ids), sl(d_am), sl(d_bb), sl(d_px), thresholds=thr, dense_rows=a.dense_rows, temperatures=temps,
-                           whole_layers=a.whole_layers, probe_always=a.probe_always)
+                           whole_layers=a.whole_layers, probe_always=a.probe_always, **({"xprobe": True} if xp else {}))
 
     # ---- the job: weak scaling = K full batches per rank; strong scaling = --total-docs dealt round-robin ----------
     strong = a.total_docs > 0
@@ -458,6 +464,17 @@ def main(argv=None):
     sync()
     dt = time.perf_counter() - t0
     layer_of_exit = np.array(list(EXIT_LAYERS) + [cfg.num_hidden_layers])
+    # A/B beside the headline (N = 1): the same steps with the K | V probe (exit rows bit-identical to the dump-all rows)
+    kv_probe_rate = None
+    if world == 1 and a.xprobe and not stub and not a.whole_layers and not strong:
+        step(xprobe=False); sync()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            o_kv = step(xprobe=False)
+        sync()
+        kv_probe_rate = a.steps * B / (time.perf_counter() - t1)
+        kv_same_exits = bool(torch.equal(o_kv.exit_layer, out.exit_layer))
+        kv_dlogit = float((o_kv.logits - out.logits).abs().max())
     # per-rank view: compute time before the all-gather, documents, mean exit layer (exit depth varies per document, so an uneven
     # deal is the one thing that can bend the scaling curve)
     my_ex = gathered[rank::world, cfg.num_labels].cpu().numpy().astype(np.int64) if world > 1 else None
@@ -493,9 +510,13 @@ def main(argv=None):
                     "reference defines no DiT exits), per-exit thresholds, synthetic pages, random-init weights"),
                    "docs_per_step_per_gpu": B, "total_docs": n_job, "text_len": T, "rows_layout": "dense" if a.dense_rows else "ragged",
                    "exit_layers": ("whole" if a.whole_layers else "probe first" if a.probe_always else
-                                   f"probe first at layers {plan_layers} (0-based; plan of a warm-up forward, pinned)"),
+                                   f"probe first at layers {plan_layers} (0-based; plan of a warm-up forward, pinned)") +
+                                  (", CLS context in X space (xprobe)" if a.xprobe else ""),
                    "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
                    "release_fraction_per_exit": a.release},
+        **({"kv_probe": {"docs_per_sec": kv_probe_rate, "what": "--no-xprobe: probe-first layers read the layer's K | V rows (bit-identical "
+                         "to whole layers) instead of the X-space CLS context", "exit_index_equal_to_headline_run": kv_same_exits,
+                         "max_abs_dlogit_vs_headline_run": kv_dlogit}} if kv_probe_rate is not None else {}),
         "mean_exit_layer": float(layer_of_exit[exits].mean()), "mean_exit_index": float(exits.mean()),
         "exit_distribution": {str(int(layer_of_exit[e])): float((exits == e).mean()) for e in range(len(layer_of_exit))},
         "stage_docs_last_step_rank0": counts["docs"], "executed_tflop_per_step_rank0": fl["total"] / 1e12,
@@ -593,6 +614,8 @@ def main(argv=None):
                 child.append("--whole-layers")
             if a.probe_always:
                 child.append("--probe-always")
+            if not a.xprobe:
+                child.append("--no-xprobe")
             # kernel-name fragments as rocprofv3 prints them
             ksub = "16>, 1, true, false, 0>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output
             passes = {}
@@ -641,7 +664,8 @@ def main(argv=None):
         srows = []
         for batch in feeder:
             o = eng.forward(batch["input_ids"], batch["attention_mask"], batch["bbox"], batch["pixel_values"], thresholds=thr,
-                            dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers, probe_always=a.probe_always)
+                            dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers, probe_always=a.probe_always,
+                            **({"xprobe": True} if a.xprobe else {}))
             srows.append(pkg.dist.pack_results(o.logits, o.exit_layer, o.confidence))
         srows = torch.cat(srows, dim=0)
         torch.cuda.synchronize()

@@ -66,10 +66,15 @@ enum {
                                   (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
     MMEE_FLAG_WHOLE_LAYERS = 4,/* run every encoder layer whole before its exit decision (what the reference does,
                                   EE/models/LayoutLMv3.py:757-768), never "probe first" (ee_last_layer_plan)          */
-    MMEE_FLAG_PROBE_ALWAYS = 8 /* probe first at every layer that ends in a decision.  With neither flag the choice is made per
+    MMEE_FLAG_PROBE_ALWAYS = 8,/* probe first at every layer that ends in a decision.  With neither flag the choice is made per
                                   exit layer from the stage populations of the handle's most recent finished forward (a probe
                                   pays when enough rows leave; the last layer is always probed).  All three give identical
                                   results bit for bit: the flags only pin the schedule, for A/B runs and tests          */
+    MMEE_FLAG_XPROBE = 16      /* probe-first layers take the CLS context in X space (csrc/xprobe.hip): score_j = (W_k^T q) . x_j + q . b_k,
+                                  ctx = W_v (sum_j p_j x_j) + b_v.  No Q | K | V projection exists when the decision is taken: the layer's
+                                  Q | K | V GEMM then runs for the documents that STAY only, and not at all in the last layer.  A
+                                  re-association of the same arithmetic (~1e-6 on the CLS row): exit indices and the 1e-4 logit bar hold,
+                                  bit-identity with MMEE_FLAG_WHOLE_LAYERS does not.  LayoutLMv3, MMEE_PREC_F32_SPLIT, no dump-all */
 };
 
 typedef struct ee_handle ee_handle;

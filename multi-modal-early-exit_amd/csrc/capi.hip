@@ -77,6 +77,9 @@ struct ee_handle {
     float* cls_f32 = nullptr;                     // split mode: CLS rows of the active documents rebuilt from the split planes
     // CLS probe (probe-first layers): one row per active document
     float *Yc = nullptr, *Ycs = nullptr, *H1c = nullptr, *Xc = nullptr, *Xcs = nullptr;
+    int* xp_order = nullptr;                      // [max_docs + 1]: documents by falling length, ticket counter
+    float *Qc = nullptr, *xp_u = nullptr, *xp_s0 = nullptr, *xp_c = nullptr;      // X-space probe (xprobe.hip): CLS queries, u, q.b_k, weighted row sums
+    std::vector<int> layer_xprobe;                // 1: the layer's probe ran in X space
     int* iota = nullptr;                          // 0 .. max_docs-1
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
     int *text_dst, *emb_pos, *ntext, *row_src, *err_flag;
@@ -498,6 +501,13 @@ int ee_create(const ee_config* c, ee_handle** out) {
                 rc |= dev_alloc(h, &h->Xc, Bm * H);
                 rc |= dev_alloc(h, &h->Xcs, Bm * H);
                 rc |= dev_alloc(h, &h->iota, Bm);
+                if (!beit) {
+                    rc |= dev_alloc(h, &h->Qc, Bm * H);
+                    rc |= dev_alloc(h, &h->xp_u, Bm * (size_t)c->num_attention_heads * H);
+                    rc |= dev_alloc(h, &h->xp_s0, Bm * (size_t)c->num_attention_heads * 2);
+                    rc |= dev_alloc(h, &h->xp_order, Bm + 1);
+                    rc |= dev_alloc(h, &h->xp_c, Bm * (size_t)c->num_attention_heads * H);
+                }
                 if (!rc) {
                     std::vector<int> io(Bm);
                     for (size_t i = 0; i < Bm; ++i) io[i] = (int)i;
@@ -891,6 +901,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     h->layer_stage.assign(L, -1);
     h->layer_qkv_stage.assign(L, -1);
     h->layer_probe_stage.assign(L, -1);
+    h->layer_xprobe.assign(L, 0);
     h->exit_stage.assign(E + 1, 0);
     const bool probe_on = !(flags & MMEE_FLAG_WHOLE_LAYERS);
     bool cls_ready = false;
@@ -1132,12 +1143,31 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // CLS probe: the layer's output for the CLS row of every active document, nothing else.  The exit head (and the final classifier)
         // only ever read that row, and a row's arithmetic does not depend on which other rows share its launch, so the value is the one
         // the whole layer would have produced, bit for bit (tests/test_gpu_api.py: early exit == the dump-all row; the dump runs whole layers).
-        auto layer_probe = [&]() {
+        auto layer_probe = [&](bool xspace) {
             ProfScope ps(h, P_PROBE, s);
             const int* nd = &h->counts[cur].n_docs;
-            AttnArgs at = attn_args();
-            at.q_limit = 32; at.max_len = max_len < 32 ? max_len : 32;     // the first 32-query block of every document; row 0 is used
-            run_attn(at);
+            if (xspace) {
+                // X-space probe (xprobe.hip): Q of the CLS rows (W_q = the first H rows of the fused weight), then the context rows without K | V
+                GemmArgs gq{};
+                gq.A = h->Xs; gq.lda = H; gq.row_src = x_phys; gq.W = w.qkv_s; gq.bias = w.qkv_b; gq.C = h->Qc; gq.ldc = H;
+                gq.alpha = w.qkv_inv / mmee::kSplitScaleX; gq.m_ptr = nd; gq.N = H; gq.K = H; gq.scale_cols = H; gq.scale = 0.125f;
+                gq.prio_mode = 1; gq.err_flag = h->err_flag; gq.probe = 1;
+                launch_gemm_split(gq, EPI_BIAS, B, cus, s);
+                mmee::XProbeArgs xa{};
+                xa.xs = reinterpret_cast<const char*>(h->Xs); xa.xs_inv = 1.0f / mmee::kSplitScaleX; xa.x_phys = x_phys; xa.doc_off = S_doc_off(cur);
+                xa.doc_orig = S_doc_orig(cur); xa.counts = &h->counts[cur]; xa.qc = h->Qc;
+                xa.wk = w.qkv_w + (size_t)H * H; xa.bk = w.qkv_b + H; xa.wv = w.qkv_w + (size_t)2 * H * H; xa.bv = w.qkv_b + 2 * H;
+                xa.u = h->xp_u; xa.s0 = h->xp_s0; xa.cvec = h->xp_c; xa.order = h->xp_order; xa.ticket = h->xp_order + B; xa.ctx = h->CTX; xa.ctx_scale = mmee::kSplitScaleCtx;
+                xa.pair_idx = h->pair_idx; xa.idx_doc_stride = h->idx_stride; xa.w1 = h->rel1; xa.wx = h->relx; xa.wy = h->rely;
+                xa.bins1 = c.rel_pos_bins; xa.bins2 = c.rel_2d_pos_bins; xa.inv_sqrt_d = 1.0f / std::sqrt((float)(H / c.num_attention_heads));
+                xa.H = H; xa.heads = c.num_attention_heads; xa.err_flag = h->err_flag;
+                mmee::launch_xprobe(xa, B, max_len, cus, s);
+                h->layer_xprobe[l] = 1;
+            } else {
+                AttnArgs at = attn_args();
+                at.q_limit = 32; at.max_len = max_len < 32 ? max_len : 32;     // the first 32-query block of every document; row 0 is used
+                run_attn(at);
+            }
             // the probe GEMMs are a few dozen tiles: static tile assignment (no queue: the pops would cost more than the tiles)
             GemmArgs g{};                    // CLS rows only: A = context row doc_off[i], residual = the document's CLS row of Xs
             g.A = h->CTX; g.lda = H; g.row_src = S_doc_off(cur); g.W = w.ao_s; g.bias = w.ao_b; g.C = h->Yc; g.ldc = H;
@@ -1167,9 +1197,37 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // every layer (the dump keeps every document to the end, so nothing would be saved)
         bool probe = probe_on && sp && !no_exit && (exit_here != last);
         if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays();
+        bool xspace = false;
+        if (probe && (flags & MMEE_FLAG_XPROBE) && use_idx && h->Qc) {
+            mmee::XProbeArgs chk{};
+            chk.H = H; chk.heads = c.num_attention_heads; chk.bins1 = c.rel_pos_bins; chk.bins2 = c.rel_2d_pos_bins; chk.pair_idx = h->pair_idx;
+            xspace = mmee::xprobe_supports(chk, max_len);
+        }
+        if (probe && xspace) {
+            // decide first, project afterwards: no Q | K | V exists yet
+            layer_probe(true);
+            if (out_hidden_cls)
+                launch_gather_cls(h->Xcs, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s,
+                                  1.0f / mmee::kSplitScaleX);
+            if (last) { cls_ready = true; break; }       // the final classifier below reads cls_f32; the last layer projects nothing
+            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);       // compacts: `cur` is now the stage of the documents that stay
+            ++next_enc;
+            // the whole layer for the documents that stay: their rows are gathered through the new row map, as after any exit
+            GemmArgs g{};
+            g.A = h->Xs; g.lda = H; g.row_src = h->row_src; g.W = w.qkv_s; g.bias = w.qkv_b; g.C = h->QKV; g.ldc = 3 * H;
+            g.alpha = w.qkv_inv / mmee::kSplitScaleX; g.out_split = 1; g.out_scale = mmee::kSplitScaleQKV;
+            g.m_ptr = &h->counts[cur].n_rows; g.N = 3 * H; g.K = H; g.scale_cols = H; g.scale = 0.125f; g.tile_counter = next_head(); g.prio_mode = 1;
+            g.err_flag = h->err_flag;
+            { ProfScope ps(h, P_GQKV, s); run_gemm(g, EPI_BIAS); }
+            h->layer_qkv_stage[l] = cur;
+            layer_rest(h->row_src, nullptr);
+            x_phys = S_doc_off(cur);
+            use_row_src = false;
+            continue;
+        }
         layer_qkv();
         if (probe) {
-            layer_probe();
+            layer_probe(false);
             if (out_hidden_cls)
                 launch_gather_cls(h->Xcs, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s,
                                   1.0f / mmee::kSplitScaleX);
@@ -1310,7 +1368,11 @@ int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int3
             if (docs_probe) docs_probe[l] = p >= 0 ? sc[p].n_docs : 0;
         }
         // probe: 32 queries x every key of the document (QK^T and PV), then attention-out + FFN on one row per document
-        if (p >= 0) pf += 4.0 * 32.0 * sc[p].n_rows * H + 2.0 * sc[p].n_docs * (H * H + 2.0 * H * I);
+        if (p >= 0) {
+            if (h->layer_xprobe[l])      // X space: q, u, v projections of one row per document + two passes of heads x H per row
+                pf += 6.0 * sc[p].n_docs * H * H + 4.0 * (double)sc[p].n_rows * c.num_attention_heads * H + 2.0 * sc[p].n_docs * (H * H + 2.0 * H * I);
+            else pf += 4.0 * 32.0 * sc[p].n_rows * H + 2.0 * sc[p].n_docs * (H * H + 2.0 * H * I);
+        }
     }
     if (probe_flops) *probe_flops = pf;
     return 0;

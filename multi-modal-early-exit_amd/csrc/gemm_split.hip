@@ -578,6 +578,7 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
     if (a.probe) {      // CLS probe: 128 x 128 tiles under their own kernel name; same MFMA form, k order and term order as CfgC => the same bits
         if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
         if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }      // Q of the CLS rows (xprobe.hip)
         // not a shape the probe launches: the default configuration below computes the same bits
     }
     if (a.out_split) {

@@ -88,6 +88,31 @@ struct DecideArgs {
     float* out_head_crit;            // (E,B)
 };
 
+// X-space CLS probe (xprobe.hip)
+struct XProbeArgs {
+    const char* xs;                  // split rows of X (LayerNorm output), H * 4 bytes per row, scaled by 1 / xs_inv
+    float xs_inv;
+    const int* x_phys;               // [n_docs] physical first (CLS) row of every active document
+    const int* doc_off;              // [n_docs + 1] dense row offsets (lengths; context rows are written at doc_off[d])
+    const int* doc_orig;             // [n_docs] original document id (pair-index slab)
+    const StageCounts* counts;
+    const float* qc;                 // [n_docs][H] Q of the CLS rows, already divided by sqrt(d)
+    const float *wk, *bk, *wv, *bv;  // key / value projection (rows h * 64 + t of the fused weight), f32
+    float *u, *s0, *cvec;            // scratch: [max_docs][heads][H], [max_docs][heads][2] (q . b_k, plane scale of u), [max_docs][heads][H]
+    int *order, *ticket;             // scratch: [max_docs] documents by falling length, [1] ticket counter of xprobe_attn_kernel
+    void* ctx;                       // out: context rows (split planes scaled by ctx_scale), row doc_off[d]
+    float ctx_scale;
+    const unsigned* pair_idx;
+    size_t idx_doc_stride;
+    const float *w1, *wx, *wy;       // raw bucket tables [heads][bins]
+    int bins1, bins2;
+    float inv_sqrt_d;
+    int H, heads;
+    int* err_flag;
+};
+bool xprobe_supports(const XProbeArgs& a, int max_len);
+void launch_xprobe(const XProbeArgs& a, int max_docs, int max_len, int num_cus, hipStream_t s);
+
 struct ImageDesc {
     long long offset;                // byte offset of the image inside the packed uint8 buffer (HWC, or HW when c == 1)
     int h, w, c, pad;

@@ -179,7 +179,7 @@ class EarlyExitEngine:
                 position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
-                validate: bool = False, whole_layers: bool = False, probe_always: bool = False) -> EngineOutput:
+                validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: bool = False) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -228,7 +228,10 @@ class EarlyExitEngine:
         hidden = torch.full((self.cfg.num_hidden_layers + 1, B, self.cfg.hidden_size), nan, dtype=torch.float32,
                             device=dev) if want_hidden_cls else None
         flags = ((capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0) |
-                 (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0))
+                 (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0) |
+                 (capi.FLAG_XPROBE if xprobe else 0))
+        # xprobe: probe-first layers take the CLS context in X space (no Q | K | V for documents that leave); same exits, logits within
+        # tolerance, not bit-identical to whole layers
         # whole_layers / probe_always pin how exit layers are scheduled (default: chosen per layer from the last forward's exits)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(dev):

@@ -390,6 +390,76 @@ def test_bench_size_early_exit_properties(pkg, oracle, precision):
     eng.close()
 
 
+def test_xspace_probe_matches_whole_layers_and_goldens(pkg, oracle):
+    """MMEE_FLAG_XPROBE (csrc/xprobe.hip): probe-first layers take the CLS context in X space and project Q | K | V only for the documents
+    that stay (HF:235-288 re-associated: (W_k^T q) . x_j and W_v sum_j p_j x_j).  Same exit indices, logits within the 1e-4 bar of the
+    whole-layer run, of the composed reference's vectors (base shape) and CLS rows; the layer plan shows the projection shrinking."""
+    # (1) base-shape golden vectors
+    g = load_golden("base_cls")
+    cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
+    eng = _engine(pkg, cfg, W, max_docs=4, T=512, precision="split")
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    for dense in (False, True):
+        for i in range(4):
+            out = eng.forward(*args, thresholds=float(g[f"pol_thr{i}"]), xprobe=True, probe_always=True, dense_rows=dense, want_hidden_cls=True,
+                              validate=True)
+            ex = _np(out.exit_layer)
+            assert np.array_equal(ex, g[f"pol_exits{i}"]), (i, dense)
+            np.testing.assert_allclose(_np(out.logits), g[f"pol_pred{i}"], rtol=0, atol=LOGIT_TOL)
+            hc = _np(out.hidden_cls)
+            ok = ~np.isnan(hc)
+            np.testing.assert_allclose(hc[ok], g["hidden_cls"][ok], rtol=0, atol=1e-4)
+            # (documents that left at the embedding exit are never probed: docs_probe may be all zero for a low threshold)
+            assert sum(eng.layer_plan()["docs_probe"]) > 0 or (ex < 1).all()
+    eng.close()
+    # (2) bench shape, 160 ragged documents: exits equal to the whole-layer run with thresholds in gaps, logits within tolerance, and the
+    # Q | K | V projection of an exit layer runs on the rows that STAY (none in the last layer)
+    ee = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.base(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=1234, head_gain=6.0)
+    B = 160
+    docs = pkg.synth.make_documents(cfg, B, seed=99, text_len=512)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=512, precision="split")
+    eng.load_weights(W)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    full = eng.forward(*args, dump_all=True, want_all=True)
+    store = _np(full.all_logits).astype(np.float64)
+    conf = oracle.softmax64(store).max(-1)
+    thr = np.full(conf.shape[0], 2.0)
+    active = np.ones(B, dtype=bool)
+    for e in range(conf.shape[0] - 1):
+        c = np.sort(conf[e, active])
+        k = int(0.75 * len(c))
+        lo, hi = max(1, k - 3), min(len(c) - 1, k + 3)
+        j = lo + int(np.argmax(c[lo:hi + 1] - c[lo - 1:hi]))
+        thr[e] = 0.5 * (c[j - 1] + c[j])
+        active &= ~(conf[e] > thr[e])
+    assert np.abs(conf[:-1] - thr[:-1, None]).min() > 1e-5               # gaps wider than the re-association noise
+    whole = eng.forward(*args, thresholds=thr, whole_layers=True, want_hidden_cls=True)
+    xp = eng.forward(*args, thresholds=thr, xprobe=True, probe_always=True, want_hidden_cls=True, validate=True)
+    sc, plan = eng.stage_counts(), eng.layer_plan()
+    assert np.array_equal(_np(xp.exit_layer), _np(whole.exit_layer))
+    np.testing.assert_allclose(_np(xp.logits), _np(whole.logits), rtol=0, atol=LOGIT_TOL)
+    np.testing.assert_allclose(_np(xp.confidence), _np(whole.confidence), rtol=0, atol=1e-4)
+    a, b = _np(xp.hidden_cls), _np(whole.hidden_cls)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert float(np.abs(a[~np.isnan(a)] - b[~np.isnan(b)]).max()) < 1e-4
+    stage_before = [sum(1 for x in ee["exits"] if x <= l) for l in range(cfg.num_hidden_layers)]
+    for l in range(cfg.num_hidden_layers):
+        last = l == cfg.num_hidden_layers - 1
+        exit_here = (l + 1) in ee["exits"]
+        want_qkv = 0 if last else sc["rows"][stage_before[l] + (1 if exit_here else 0)]       # projected AFTER the decision: the rows that stay
+        assert plan["rows_qkv"][l] == want_qkv, (l, plan["rows_qkv"], sc)
+        assert plan["rows_main"][l] == want_qkv
+        assert plan["docs_probe"][l] == (sc["docs"][stage_before[l]] if (exit_here or last) else 0)
+    # the default schedule with xprobe gives the same exits too
+    d2 = eng.forward(*args, thresholds=thr, xprobe=True)
+    assert np.array_equal(_np(d2.exit_layer), _np(whole.exit_layer))
+    eng.close()
+
+
 def test_exit_layer_schedule_follows_the_last_forward(pkg, oracle):
     """Split precision decides per exit layer whether to probe first, from the stage populations of the handle's most recent FINISHED
     thresholded forward (ee_forward flags, include/mmee.h): with many leavers the exit layer is probed, with hardly any it is run whole,
