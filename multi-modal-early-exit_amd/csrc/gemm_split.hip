@@ -168,6 +168,14 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
 // 16 on rows whose (row >> 2) is odd, so the two 16-lane groups of a 32-lane write group hit disjoint banks.
 // RB = rows staged at a time (32: 8 KB per wave; 16: 4 KB per wave, so that the 16 waves' staging fits ONE ring slot and the other
 // slot can already receive the next tile's first stage while this epilogue runs).
+// The residual epilogue (attention-output and FFN-down GEMMs) is the expensive one: N = 768, K = 768 runs at 290-295 algorithmic TFLOP/s
+// with it and at 380 with the bias epilogue on the same operands, N = 2304 at 341 against 411 (tools/gemm_attn_out_why.py,
+// profiles/r03_gemm_attn_out_why.txt): ~19 us per 256 x 256 tile for 256 KB of residual that the k-loop of the ONE workgroup on the CU
+// cannot hide.  Measured on top of this form, none moved the kernel: (1) touching the sub-tile's 128 residual lines eight stages before the
+// end of the k-loop (dword LDS-DMA into a scratch strip: no register, no compiler wait) -- 284 vs 284; (2) branch-free fetches of 16 rows
+// at a time issued as soon as the previous 16 rows' registers are free -- 290, +5 spilled registers at the 128-VGPR cap; (3) the same with
+// two register sets -- 21 spills.  What remains is holding the first rows' residual across the last k-stages, which needs 16 registers
+// the 16-wave configuration does not have, or 4 KB of LDS per wave where 2 KB are free.
 template <int EPI, bool OUT_SPLIT, int WN, int RB>
 __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* smem, f32x4 (&acc)[4][4], int m0, int n0, int M,
                                                    int wave, int lane, const f32x4 bv, const f32x4 lam) {
