@@ -174,8 +174,11 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
 // cannot hide.  Measured on top of this form, none moved the kernel: (1) touching the sub-tile's 128 residual lines eight stages before the
 // end of the k-loop (dword LDS-DMA into a scratch strip: no register, no compiler wait) -- 284 vs 284; (2) branch-free fetches of 16 rows
 // at a time issued as soon as the previous 16 rows' registers are free -- 290, +5 spilled registers at the 128-VGPR cap; (3) the same with
-// two register sets -- 21 spills.  What remains is holding the first rows' residual across the last k-stages, which needs 16 registers
-// the 16-wave configuration does not have, or 4 KB of LDS per wave where 2 KB are free.
+// two register sets -- 21 spills; (4) the add moved into the LayerNorm kernel that follows (bias epilogue + f32 store + residual there: the
+// same bits, all 57 GPU tests green): attention-output share of the step 8.1 -> 6.3 %, FFN-down 22.5 -> 21.2 %, LayerNorm 5.0 -> 8.0 %,
+// 6750 vs 6757 docs/s -- the 0.73 GB cost the same HBM time wherever they are read, so the residual stays here.  What remains is holding
+// the first rows' residual across the last k-stages, which needs 16 registers the 16-wave configuration does not have, or 4 KB of LDS
+// per wave where 2 KB are free.
 template <int EPI, bool OUT_SPLIT, int WN, int RB>
 __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* smem, f32x4 (&acc)[4][4], int m0, int n0, int M,
                                                    int wave, int lane, const f32x4 bv, const f32x4 lam) {
