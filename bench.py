@@ -466,7 +466,7 @@ def main(argv=None):
     layer_of_exit = np.array(list(EXIT_LAYERS) + [cfg.num_hidden_layers])
     # A/B beside the headline (N = 1): the same steps with the K | V probe (exit rows bit-identical to the dump-all rows)
     kv_probe_rate = None
-    if world == 1 and a.xprobe and not stub and not a.whole_layers and not strong:
+    if world == 1 and a.xprobe and not stub and not a.whole_layers and not strong and not a.thresholds:   # (not in the pinned profile / PMC child runs)
         step(xprobe=False); sync()
         t1 = time.perf_counter()
         for _ in range(a.steps):

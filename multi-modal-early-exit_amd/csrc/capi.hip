@@ -40,6 +40,8 @@ struct LayerW {
 };
 struct HeadW {
     float *dense_w = nullptr, *dense_b = nullptr, *out_w = nullptr, *out_b = nullptr;
+    float* dense_s = nullptr;           // split precision: split-f16 rows of dense_w (the head's dense runs on the split GEMM kernel)
+    float dense_inv = 1.f;
     int out_dim = 0;
 };
 
@@ -670,6 +672,12 @@ int ee_finalize(ee_handle* h) {
             if (build(w.f1_w, I, H, &w.f1_s, &w.f1_inv)) return 1;
             if (build(w.f2_w, H, I, &w.f2_s, &w.f2_inv)) return 1;
         }
+        // the dense layer of every exit head and of the classifier (EE/models/LayoutLMv3.py:86-93, HF:799-823): H x H, on CLS rows
+        if (mmee::gemm_split_supports(H, H) && c.arch != MMEE_ARCH_BEIT) {
+            auto head = [&](HeadW& hw) -> int { return hw.dense_w ? build(hw.dense_w, H, H, &hw.dense_s, &hw.dense_inv) : 0; };
+            for (auto& hw : h->enc_heads) if (head(hw)) return 1;
+            if (head(h->classifier)) return 1;
+        }
         const int Kp = c.num_channels * c.patch_size * c.patch_size;
         const size_t NPp = (size_t)(c.input_size / c.patch_size) * (c.input_size / c.patch_size);
         const bool fits = NPp * Kp <= ((size_t)c.max_text_len + NPp + 1) * I;      // the split patches are staged in H1
@@ -906,12 +914,22 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     const bool probe_on = !(flags & MMEE_FLAG_WHOLE_LAYERS);
     bool cls_ready = false;
 
-    auto run_head = [&](const HeadW& hw, const float* in, int ld, const int* gather, float* hid, float* out) {
+    // in_split / split_rows: the same input rows as split planes (LayerNorm outputs scaled by kSplitScaleX), when they exist: the head's
+    // dense then runs on the split GEMM kernel (128 x 128 tiles of the CLS-probe launches) instead of the f32 MFMA kernel
+    auto run_head = [&](const HeadW& hw, const float* in, int ld, const int* gather, float* hid, float* out, const float* in_split,
+                        const int* split_rows) {
         const int* n_docs_ptr = &h->counts[cur].n_docs;
         const float* hin = in;
         int hld = ld;
         const int* hg = gather;
-        if (hw.dense_w) {
+        if (hw.dense_w && hw.dense_s && in_split) {
+            GemmArgs g{};
+            g.A = in_split; g.lda = H; g.row_src = split_rows; g.W = hw.dense_s; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
+            g.m_ptr = n_docs_ptr; g.N = H; g.K = H; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag; g.probe = 1;
+            g.alpha = hw.dense_inv / mmee::kSplitScaleX;
+            launch_gemm_split(g, EPI_TANH, B, cus, s);
+            hin = hid; hld = H; hg = nullptr;
+        } else if (hw.dense_w) {
             GemmArgs g{};
             g.A = in; g.lda = ld; g.row_src = gather; g.W = hw.dense_w; g.bias = hw.dense_b; g.C = hid; g.ldc = H;
             // a handful of tiles: static assignment (walking the eight XCD queues would cost more than the tiles)
@@ -925,23 +943,24 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         { ProfScope po(h, P_HEADOUT, s); launch_head_out(ho, B, s); }
     };
 
-    auto run_exit = [&](const HeadW* hw, const float* in, int ld, const int* gather, bool is_final) {
+    auto run_exit = [&](const HeadW* hw, const float* in, int ld, const int* gather, bool is_final, const float* in_split = nullptr,
+                        const int* split_rows = nullptr) {
         const float* pol;
         const float* head = nullptr;
         int Kh = K;
         ProfScope* hs = new ProfScope(h, P_HEAD, s);
         if (is_final) {
-            run_head(h->classifier, in, ld, gather, h->hid, h->pol_logits);
+            run_head(h->classifier, in, ld, gather, h->hid, h->pol_logits, in_split, split_rows);
             pol = h->pol_logits;
         } else if (c.strategy == MMEE_STRATEGY_GATE) {
             // the policy only ever sees classifier(gate input) (EE/utils.py:183-188); the 2-way gate logits (exit_states) are
             // computed when the caller asked for them (the dump of model.forward), not in the fast path
             const bool want_gate = out_head_logits || out_head_crit;
-            if (want_gate) run_head(*hw, in, ld, gather, h->hid, h->head_logits);
-            run_head(h->classifier, in, ld, gather, h->hid2, h->pol_logits);  // gated_logits, EE/models/LayoutLMv3.py:768
+            if (want_gate) run_head(*hw, in, ld, gather, h->hid, h->head_logits, in_split, split_rows);
+            run_head(h->classifier, in, ld, gather, h->hid2, h->pol_logits, in_split, split_rows);  // gated_logits, EE/models/LayoutLMv3.py:768
             pol = h->pol_logits; head = want_gate ? h->head_logits : nullptr; Kh = head_dim_out;
         } else {
-            run_head(*hw, in, ld, gather, h->hid, h->head_logits);
+            run_head(*hw, in, ld, gather, h->hid, h->head_logits, in_split, split_rows);
             pol = h->head_logits; head = h->head_logits; Kh = K;
         }
         delete hs;
@@ -1210,7 +1229,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                 launch_gather_cls(h->Xcs, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s,
                                   1.0f / mmee::kSplitScaleX);
             if (last) { cls_ready = true; break; }       // the final classifier below reads cls_f32; the last layer projects nothing
-            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);       // compacts: `cur` is now the stage of the documents that stay
+            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false, h->Xcs, nullptr);       // compacts: `cur` is now the stage of the documents that stay
             ++next_enc;
             // the whole layer for the documents that stay: their rows are gathered through the new row map, as after any exit
             GemmArgs g{};
@@ -1232,7 +1251,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                 launch_gather_cls(h->Xcs, H, h->iota, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls + (size_t)(l + 1) * B * H, B, s,
                                   1.0f / mmee::kSplitScaleX);
             if (last) { cls_ready = true; break; }       // the final classifier below reads cls_f32
-            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);       // compacts: `cur` is now the stage of the documents that stay
+            run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false, h->Xcs, nullptr);       // compacts: `cur` is now the stage of the documents that stay
             ++next_enc;
             // the rest of the layer, for those documents only; their Q | K | V rows are where the previous stage's numbering put them
             layer_rest(h->row_src, S_meta_src(cur));
@@ -1253,7 +1272,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1) {
             if (x_is_split) {
                 launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, xs_inv);
-                run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false);
+                run_exit(&h->enc_heads[next_enc], h->cls_f32, H, nullptr, false, h->Xs, x_phys);
             } else {
                 run_exit(&h->enc_heads[next_enc], h->X, H, x_phys, false);
             }
@@ -1267,7 +1286,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         run_exit(nullptr, h->pooled[0], H, nullptr, true);
     } else if (sp && L > 0) {
         if (!cls_ready) launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
-        run_exit(nullptr, h->cls_f32, H, nullptr, true);
+        run_exit(nullptr, h->cls_f32, H, nullptr, true, cls_ready ? h->Xcs : h->Xs, cls_ready ? nullptr : x_phys);
     } else {
         run_exit(nullptr, h->X, H, x_phys, true);
     }

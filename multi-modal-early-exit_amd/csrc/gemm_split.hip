@@ -590,6 +590,7 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
         if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
         if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
         if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }      // Q of the CLS rows (xprobe.hip)
+        if (!a.out_split && epi == EPI_TANH) { launch_split_one<CfgP, EPI_TANH, false, false, 1>(a, max_m, num_cus, s); return; }      // dense + tanh of an exit head
         // not a shape the probe launches: the default configuration below computes the same bits
     }
     if (a.out_split) {
