@@ -58,7 +58,7 @@ struct SplitCfg {
     static_assert(BM == WM * 64 && BN == WN * 64, "one 64x64 sub-tile per wave");
     static_assert(PA * PROWS * NW == BM && PW * PROWS * NW == BN && PA >= 1 && PW >= 1, "DMA pieces must tile the stage");
     static_assert(EPI_BYTES <= LOOP_BYTES, "epilogue staging must fit in the stage ring");
-    static_assert(NST == 2 || NST == 3, "ring depth");
+    static_assert(NST >= 2 && NST <= 4, "ring depth");
     // refused at compile time rather than at launch: a configuration the CU cannot hold (round 2's 128 x 64 sub-tile experiment died with
     // SIGABRT inside ee_debug_gemm_split's GELU / split-output case and left no diagnostic)
     static_assert(THREADS <= 1024, "a workgroup is at most 16 waves");
@@ -74,8 +74,9 @@ using CfgC = SplitCfg<256, 256, 128, 2, 4, 4, 1, 16>;
 // CfgP: the CLS-probe GEMMs (M = documents of the stage, a few hundred rows).  Those launches are a handful of tiles whose k-loop
 // is bound by the latency of a stage, not by the matrix pipe.  Measured on the six probes of one bench step (three GEMMs each):
 // CfgC 1.80 ms, 64x128 on 2 waves 1.73 ms, 128x256 on 8 waves 1.26 ms, 128x128 on 4 waves with the 3-deep ring 0.91 ms (one wave
-// per SIMD, two stages in flight).  Per output element the MFMA sequence is CfgC's (same 16x16x32 form, same k order, same term
-// order), so the results are CfgC's bit for bit.
+// per SIMD, two stages in flight).  Round 3: a 4-deep ring (three stages = 96 KB in flight per CU; the ring code takes NST = 4) is
+// SLOWER end to end, 6669 against 6704 docs/s on one box (tools/lib_ab.sh).  Per output element the MFMA sequence is CfgC's (same
+// 16x16x32 form, same k order, same term order), so the results are CfgC's bit for bit.
 using CfgP = SplitCfg<128, 128, 128, 3, 2, 2, 1, 16>;
 
 bool gemm_split_supports(int N, int K) { return N > 0 && K > 0 && N % 256 == 0 && K % 32 == 0; }
@@ -386,7 +387,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     }
     // ring: stage kt lives in slot (buf0 + kt) % NST; NST - 1 stages are in flight ahead of the one being consumed
     issue(cur, 0, buf0);
-    if (NST == 3 && nk > 1) issue(cur, 1, 1);
+    if (NST >= 3 && nk > 1) issue(cur, 1, 1);
+    if (NST >= 4 && nk > 2) issue(cur, 2, 2);
     for (;;) {
         const int m0 = cur.m0, n0 = cur.n0;
         f32x16 acc[2][2];
@@ -416,7 +418,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else if (dbg & 4) {                    // diagnostic: no DMA wait
                 asm volatile("s_barrier" ::: "memory");
-            } else if (NST == 3 && kt + 1 < nk) {
+            } else if (NST == 4 && kt + 2 < nk) {      // two younger stages may still be in flight
+                static_assert(NST != 4 || Cfg::PP == 8, "vmcnt immediate: two stages' pieces per wave");
+                asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            } else if (NST >= 3 && kt + 1 < nk) {
                 static_assert(Cfg::PP == 3 || Cfg::PP == 4 || Cfg::PP == 8, "vmcnt immediate: one stage's pieces per wave");
                 if (Cfg::PP == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
                 else if (Cfg::PP == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
@@ -508,7 +513,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
         buf0 = nbuf0;
         if (!HANDOVER) {
             issue(cur, 0, 0);
-            if (NST == 3 && nk > 1) issue(cur, 1, 1);
+            if (NST >= 3 && nk > 1) issue(cur, 1, 1);
+            if (NST >= 4 && nk > 2) issue(cur, 2, 2);
         }
     }
     if (DIAG && g.clk_probe && threadIdx.x == 0) {      // diagnostic: shader clock = d(memtime) / d(memrealtime) * 100 MHz
