@@ -3,7 +3,7 @@
 # usage: bash tools/profile_round.sh r02     -> gpurun_out/<tag>_kernel_stats.csv, gpurun_out/<tag>_pmc_summary.csv
 set -o pipefail
 TAG=${1:-rXX}
-THR=${THR:-0.520425,0.550076,0.503619,0.428325,0.88321}
+THR=${THR:-0.526068,0.546771,0.506562,0.430061,0.883177}      # thresholds of the default bench (B = 1024, release 0.2)
 OUT=$PWD/gpurun_out
 ROOT=$PWD
 mkdir -p $OUT

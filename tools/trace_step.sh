@@ -3,7 +3,7 @@
 #   bash tools/trace_step.sh tag   -> gpurun_out/<tag>_trace.csv  (kernel, start_ns, dur_us)
 set -o pipefail
 TAG=${1:-trace}
-THR=${THR:-0.520425,0.550076,0.503619,0.428325,0.88321}
+THR=${THR:-0.526068,0.546771,0.506562,0.430061,0.883177}      # thresholds of the default bench (B = 1024, release 0.2)
 OUT=$PWD/gpurun_out
 ROOT=$PWD
 mkdir -p $OUT
