@@ -1175,7 +1175,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                 mmee::XProbeArgs xa{};
                 xa.xs = reinterpret_cast<const char*>(h->Xs); xa.xs_inv = 1.0f / mmee::kSplitScaleX; xa.x_phys = x_phys; xa.doc_off = S_doc_off(cur);
                 xa.doc_orig = S_doc_orig(cur); xa.counts = &h->counts[cur]; xa.qc = h->Qc;
-                xa.wk = w.qkv_w + (size_t)H * H; xa.bk = w.qkv_b + H; xa.wv = w.qkv_w + (size_t)2 * H * H; xa.bv = w.qkv_b + 2 * H;
+                xa.wk = w.qkv_w + (size_t)H * H; xa.bk = w.qkv_b + H; xa.wv_s = w.qkv_s + (size_t)2 * H * H; xa.wv_inv = w.qkv_inv; xa.bv = w.qkv_b + 2 * H;
                 xa.u = h->xp_u; xa.s0 = h->xp_s0; xa.cvec = h->xp_c; xa.order = h->xp_order; xa.ticket = h->xp_order + B; xa.ctx = h->CTX; xa.ctx_scale = mmee::kSplitScaleCtx;
                 xa.pair_idx = h->pair_idx; xa.idx_doc_stride = h->idx_stride; xa.w1 = h->rel1; xa.wx = h->relx; xa.wy = h->rely;
                 xa.bins1 = c.rel_pos_bins; xa.bins2 = c.rel_2d_pos_bins; xa.inv_sqrt_d = 1.0f / std::sqrt((float)(H / c.num_attention_heads));

@@ -97,7 +97,9 @@ struct XProbeArgs {
     const int* doc_orig;             // [n_docs] original document id (pair-index slab)
     const StageCounts* counts;
     const float* qc;                 // [n_docs][H] Q of the CLS rows, already divided by sqrt(d)
-    const float *wk, *bk, *wv, *bv;  // key / value projection (rows h * 64 + t of the fused weight), f32
+    const float *wk, *bk, *bv;       // key projection and the biases (rows h * 64 + t of the fused weight), f32
+    const float* wv_s;               // value projection as split-f16 rows (the fused Q | K | V weight of ee_finalize), scaled by 1 / wv_inv
+    float wv_inv;
     float *u, *s0, *cvec;            // scratch: [max_docs][heads][H], [max_docs][heads][2] (q . b_k, plane scale of u), [max_docs][heads][H]
     int *order, *ticket;             // scratch: [max_docs] documents by falling length, [1] ticket counter of xprobe_attn_kernel
     void* ctx;                       // out: context rows (split planes scaled by ctx_scale), row doc_off[d]

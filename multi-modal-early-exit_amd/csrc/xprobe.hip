@@ -19,6 +19,7 @@
 //                          attention-output GEMM expects it.
 // The result is a re-association of the whole-layer arithmetic (~1e-6 apart, inside the 1e-4 bar): with this flag "early exit == dump-all
 // row bit for bit" holds to tolerance, not to the bit; MMEE_FLAG_WHOLE_LAYERS and the default probe stay bit-identical to each other.
+#include <type_traits>
 #include "mmee_kernels.h"
 
 namespace mmee {
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
         // ---- e. normalise: lane (col m of the group, heads 4 kq + r) ----
         l_run += __shfl_xor(l_run, 16, 64);
         l_run += __shfl_xor(l_run, 32, 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        auto store_head = [&](auto rc) __attribute__((always_inline)) {      // (a lambda per register: `#pragma unroll` over r trips -Wpass-failed here)
+            constexpr int r = decltype(rc)::value;
             const int h = 4 * kq + r;
             const float lh = __shfl(l_run, h, 64);
             if (h < heads) {
@@ -318,57 +319,78 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
 #pragma unroll
                 for (int i = 0; i < 6; ++i) a.cvec[((size_t)d * heads + h) * H + (6 * wave + i) * 16 + m] = cacc[i][r] * f;
             }
-        }
+        };
+        store_head(std::integral_constant<int, 0>{});
+        store_head(std::integral_constant<int, 1>{});
+        store_head(std::integral_constant<int, 2>{});
+        store_head(std::integral_constant<int, 3>{});
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // ctx[d][h*64 + t] = sum_c W_v[h*64 + t][c] c[d][h][c] + b_v[h*64 + t]  ->  split planes at context row doc_off[d]
-// grid (heads, ceil(max_docs / 8)); thread <-> (t = tid & 63, quarter of the columns = tid >> 6)
+// A [documents x H] . [H x 64] product per head on the f16 matrix cores: one wave = 16 documents x the 64 outputs of a head.  A = c
+// (f32 from xprobe_attn_kernel, split in registers with the scale of the LayerNorm planes: |c| <= max |x|), B = the rows of the layer's
+// split-f16 value weights (the fused Q | K | V weight of ee_finalize, 16 bytes per lane and k-step straight from global memory / L2);
+// three terms per product as everywhere.  grid (heads, ceil(max_docs / 64)), 4 waves.  (The first version walked the f32 weights with
+// VALU dot products, 8 documents per workgroup: 122 us at 1024 documents against 27 for this one.)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xprobe_v_kernel(const XProbeArgs a) {
-    const int n_docs = a.counts->n_docs, H = a.H;
-    const int h = blockIdx.x, d0 = blockIdx.y * 8;
-    if (d0 >= n_docs) return;
-    extern __shared__ __attribute__((aligned(16))) char vsm[];
-    float* cs = reinterpret_cast<float*>(vsm);                     // [8][H]
-    float* red = cs + 8 * H;                                       // [4][8][64]
-    const int tid = threadIdx.x, t = tid & 63, part = tid >> 6;
-    for (int i = tid; i < 8 * H; i += 256) {
-        const int g = i / H, c = i - g * H, d = d0 + g;
-        cs[i] = d < n_docs ? a.cvec[((size_t)d * a.heads + h) * H + c] : 0.f;
-    }
-    __syncthreads();
-    float acc[8];
+    constexpr int H = 768;                                         // xprobe_supports
+    const int n_docs = a.counts->n_docs;
+    const int h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d0 = (blockIdx.y * 4 + wave) * 16;
+    if (d0 >= n_docs) return;                                      // wave-uniform
+    const int m = lane & 15, kq = lane >> 4;
+    const int dm = d0 + m < n_docs ? d0 + m : n_docs - 1;
+    const float* cp = a.cvec + ((size_t)dm * a.heads + h) * H + 8 * kq;
+    const char* wp = reinterpret_cast<const char*>(a.wv_s) + (size_t)(h * 64 + m) * H * 4 + (kq >> 1) * 64 + (kq & 1) * 16;
+    const size_t wtile = (size_t)16 * H * 4;                       // 16 output rows further
+    constexpr float kSc = 16.0f;                                   // = kSplitScaleX
+    f32x4 acc[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc[g] = 0.f;
-    const int cw = H / 4;
-    const float* wr = a.wv + (size_t)(h * 64 + t) * H + part * cw;
-    const float* cp = cs + part * cw;
-#pragma unroll 4
-    for (int c = 0; c < cw; c += 4) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int ks = 0; ks < H / 32; ++ks) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp + 32 * ks), c1 = *reinterpret_cast<const f32x4*>(cp + 32 * ks + 4);
+        f16x8 ah, al;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(cp + g * H + c);
-            acc[g] += (w[0] * x[0] + w[1] * x[1]) + (w[2] * x[2] + w[3] * x[3]);
+        for (int e = 0; e < 8; ++e) {
+            const float v = (e < 4 ? c0[e] : c1[e - 4]) * kSc;
+            const _Float16 hi = (_Float16)v;
+            ah[e] = hi;
+            al[e] = (_Float16)(v - (float)hi);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(wp + j * wtile + 128 * ks);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(wp + j * wtile + 128 * ks + 32);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[j], 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) red[(part * 8 + g) * 64 + t] = acc[g];
-    __syncthreads();
+    // acc[j][r] <-> (document d0 + 4 kq + r, output 16 j + m): bias, then the split planes of the context row (one f16 per plane and lane:
+    // 16 lanes write 32 contiguous bytes)
+    const float inv = a.wv_inv / kSc;
     float amax = 0.f;
-    if (tid < 8 * 16) {                                            // 8 documents x 16 groups of four columns
-        const int g = tid >> 4, q4 = tid & 15, d = d0 + g;
-        if (d < n_docs) {
-            f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int tt = 4 * q4 + e;
-                v[e] = ((red[(0 * 8 + g) * 64 + tt] + red[(1 * 8 + g) * 64 + tt]) + (red[(2 * 8 + g) * 64 + tt] + red[(3 * 8 + g) * 64 + tt])) + a.bv[h * 64 + tt];
+    for (int j = 0; j < 4; ++j) {
+        const int col = h * 64 + 16 * j + m;
+        const float bias = a.bv[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = d0 + 4 * kq + r;
+            if (d < n_docs) {
+                const float v = (acc[j][r] * inv + bias) * a.ctx_scale;
+                amax = fmaxf(amax, fabsf(v));
+                const float vc = fminf(fmaxf(v, -kSplitClamp), kSplitClamp);
+                const _Float16 hi = (_Float16)vc;
+                const _Float16 lo = (_Float16)(vc - (float)hi);
+                char* row = reinterpret_cast<char*>(a.ctx) + (size_t)a.doc_off[d] * H * 4 + (size_t)(col >> 4) * 64 + (size_t)(col & 15) * 2;
+                *reinterpret_cast<_Float16*>(row) = hi;
+                *reinterpret_cast<_Float16*>(row + 32) = lo;
             }
-            char* row = reinterpret_cast<char*>(a.ctx) + (size_t)a.doc_off[d] * H * 4;
-            store_split4(row, h * 64 + 4 * q4, v, a.ctx_scale, amax);
         }
     }
     split_flag_overflow(amax, a.err_flag);
@@ -398,8 +420,7 @@ void launch_xprobe(const XProbeArgs& a, int max_docs, int max_len, int num_cus, 
     int grid = max_docs < num_cus ? max_docs : num_cus;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL((xprobe_attn_kernel<12>), dim3(grid), dim3(XP_THREADS), lds, s, a, tstr, off_tab, off_part, off_idx, npad);
-    const int vlds = (8 * a.H + 4 * 8 * 64) * 4;
-    hipLaunchKernelGGL(xprobe_v_kernel, dim3(a.heads, groups), dim3(256), vlds, s, a);
+    hipLaunchKernelGGL(xprobe_v_kernel, dim3(a.heads, (max_docs + 63) / 64), dim3(256), 0, s, a);
 }
 
 }  // namespace mmee
