@@ -714,8 +714,8 @@ int ee_finalize(ee_handle* h) {
     bucket_lut_host(c.rel_pos_bins, c.max_rel_pos, h->c1, l1.data());
     bucket_lut_host(c.rel_2d_pos_bins, c.max_rel_2d_pos, h->c2, l2.data());
     if (!h->lut1_dev) {
-        if (dev_alloc(h, &h->lut1_dev, (size_t)h->n1)) return 1;
-        if (dev_alloc(h, &h->lut2_dev, (size_t)h->n2)) return 1;
+        if (dev_alloc(h, &h->lut1_dev, (size_t)h->n1 + 4)) return 1;      // + 4: pair_index_kernel stages them as whole words
+        if (dev_alloc(h, &h->lut2_dev, (size_t)h->n2 + 4)) return 1;
     }
     unsigned char *d1 = h->lut1_dev, *d2 = h->lut2_dev;      // kept: the per-forward pair index is built from them
     HIP_OK(h, hipMemcpy(d1, l1.data(), h->n1, hipMemcpyHostToDevice));
@@ -852,8 +852,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         launch_prep(pa, s);
         if (h->pair_idx && use_idx) {    // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
             ProfScope pi(h, P_PAIRIDX, s);
-            mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->lut2_dev, h->c2, c.rel_pos_bins,
-                                    h->pair_idx, h->idx_stride, s);
+            mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
+                                    h->pair_idx, h->idx_stride, max_len, s);
         }
     }
 

@@ -297,8 +297,8 @@ unsigned long long* attention_pair_stamps();
 unsigned long long* attention_idx_stamps();
 bool attention_idx_supports(const AttnArgs& a);
 void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
-void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1,
-                       const unsigned char* lut2, int c2, int bins1, unsigned* out, size_t doc_stride, hipStream_t s);
+void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1, int n1,
+                       const unsigned char* lut2, int c2, int n2, int bins1, unsigned* out, size_t doc_stride, int max_len, hipStream_t s);
 bool attention_pair_supports(const AttnArgs& a, int max_rel_pos, int max_rel_2d_pos);
 void launch_attention_pair(const AttnArgs& a, int max_docs, int num_cus, int max_rel_pos, int max_rel_2d_pos, int any_masked, hipStream_t s);
 size_t gemm_f32_lds_bytes();
