@@ -185,6 +185,9 @@ int dev_alloc(ee_handle* h, T** p, size_t count) {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, count * sizeof(T) + 256);
     if (e != hipSuccess) return fail(h, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    // the allocator hands back whatever the previous owner left: zero it, so that no kernel can ever act on another handle's stale
+    // counters or indices (tools/fuzz_schedules.py found a stale ticket counter this way; a few milliseconds per handle)
+    if (hipMemset(q, 0, count * sizeof(T) + 256) != hipSuccess) return fail(h, "hipMemset of a new allocation failed");
     h->allocs.push_back(q);
     *p = reinterpret_cast<T*>(q);
     return 0;

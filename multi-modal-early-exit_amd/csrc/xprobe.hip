@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void xprobe_u_kernel(const XProbeArgs a) {
     const int n_docs = a.counts->n_docs, H = a.H;
     const int h = blockIdx.x, d0 = blockIdx.y * 8;
     const int tid = threadIdx.x;
+    // the ticket counter of xprobe_attn_kernel is reset by EVERY launch, also when the stage is empty (n_docs == 0: the workspace is not
+    // zeroed by the allocator, and a stale negative ticket would pass the `ticket < n_docs` test of the consumer)
+    if (h == 0 && blockIdx.y == 0 && tid == 0) *a.ticket = 0;
     if (d0 >= n_docs) return;
     if (h == 0) {
         // work order of xprobe_attn_kernel: longest document first (its workgroups draw tickets; the makespan of a ragged stage is then the
@@ -54,7 +57,6 @@ __global__ __launch_bounds__(256) void xprobe_u_kernel(const XProbeArgs a) {
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) rank += __shfl_xor(rank, o, 64);
         if (sub == 0 && d < n_docs) a.order[rank] = d;
-        if (blockIdx.y == 0 && tid == 0) *a.ticket = 0;
     }
     __shared__ float q_s[8][64];
     for (int i = tid; i < 512; i += 256) {
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
         if (tid == 0) *tick_s = atomicAdd(a.ticket, 1);
         __syncthreads();
         const int tk = __builtin_amdgcn_readfirstlane(*tick_s);
-        if (tk >= n_docs) break;
+        if ((unsigned)tk >= (unsigned)n_docs) break;
         const int d = __builtin_amdgcn_readfirstlane(a.order[tk]);
         const int off = a.doc_off[d], len = a.doc_off[d + 1] - off;
         const char* x0 = a.xs + (size_t)a.x_phys[d] * ROWB;

@@ -399,7 +399,7 @@ def test_xspace_probe_matches_whole_layers_and_goldens(pkg, oracle):
     cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
     W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
     docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
-    eng = _engine(pkg, cfg, W, max_docs=4, T=512, precision="split")
+    eng0 = eng = _engine(pkg, cfg, W, max_docs=4, T=512, precision="split")
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
     for dense in (False, True):
         for i in range(4):
@@ -413,7 +413,12 @@ def test_xspace_probe_matches_whole_layers_and_goldens(pkg, oracle):
             np.testing.assert_allclose(hc[ok], g["hidden_cls"][ok], rtol=0, atol=1e-4)
             # (documents that left at the embedding exit are never probed: docs_probe may be all zero for a low threshold)
             assert sum(eng.layer_plan()["docs_probe"]) > 0 or (ex < 1).all()
-    eng.close()
+    # (1b) empty stages: every document leaves at the embedding exit, so each probe of the encoder runs on zero documents (the ticket
+    # counter of the probe kernel must not depend on what the workspace held before: tools/fuzz_schedules.py, round 3)
+    for _ in range(2):
+        out = eng0.forward(*args, thresholds=0.0, xprobe=True, probe_always=True, validate=True)
+        assert (_np(out.exit_layer) == 0).all() and eng0.layer_plan()["rows_qkv"] == [0] * cfg.num_hidden_layers
+    eng0.close()
     # (2) bench shape, 160 ragged documents: exits equal to the whole-layer run with thresholds in gaps, logits within tolerance, and the
     # Q | K | V projection of an exit layer runs on the rows that STAY (none in the last layer)
     ee = dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp")

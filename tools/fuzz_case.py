@@ -1,0 +1,78 @@
+"""One case of tools/fuzz_schedules.py replayed with a progress line before every forward (GPU box only; diagnosis of a failing case):
+python tools/fuzz_case.py <case index>     -- replays the generator of fuzz_schedules.py up to that case and runs only it."""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fuzz_schedules as fz
+pkg = fz.pkg
+_np = fz._np
+want = int(sys.argv[1])
+# the generator's stream position depends on the threshold draws of the earlier cases: replay them from the recorded populations
+draws = {0: [], 1: [5, 3, 2], 2: [96, 79]}     # len(c) of every draw of cases 0..2 (from the printed populations of the failing run)
+rng = np.random.default_rng(2026)
+import torch
+
+
+def params(rng):
+    L = int(rng.integers(2, 6))
+    exits = sorted(rng.choice(np.arange(1, L + 1), size=int(rng.integers(1, L + 1)), replace=False).tolist())
+    strat = ["ramp", "gate"][int(rng.integers(0, 2))]
+    emb = [[], ["vision_avg"], ["text_avg", "text_visual_concat"]][int(rng.integers(0, 3))]
+    H = [256, 768][int(rng.integers(0, 2))]
+    B = int(rng.choice([1, 5, 33, 96])); T = int(rng.choice([16, 130, 512]))
+    ws = int(rng.integers(1, 1 << 30)); ds = int(rng.integers(1, 1 << 30))
+    E1 = len(emb + exits) + 1
+    temps = rng.uniform(0.5, 3.0, size=E1) if rng.integers(0, 2) else None
+    dense = bool(rng.integers(0, 2))
+    return L, emb + exits, strat, H, B, T, ws, ds, temps, dense, E1
+
+
+for case in range(want):
+    params(rng)
+    for n in draws[case]:
+        rng.integers(1, n)
+L, exits, strat, H, B, T, ws, ds, temps, dense, E1 = params(rng)
+print(f"case {want}: L={L} H={H} exits={exits} {strat} B={B} T={T} dense={dense} temps={temps}", flush=True)
+ee = dict(exits=exits, encoder_layer_strategy=strat)
+cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=L, hidden_size=H, intermediate_size=4 * H if H == 768 else 512,
+                           num_attention_heads=H // 64, coordinate_size=40 if H == 256 else 128, shape_size=48 if H == 256 else 128)
+if len(sys.argv) > 2:      # poison: freed device memory keeps this pattern, so a kernel that reads a buffer nobody initialised uses it
+    pat = int(sys.argv[2], 0)
+    junk = [torch.full((1 << 28,), pat, dtype=torch.int32, device="cuda") for _ in range(24)]      # 24 GiB
+    torch.cuda.synchronize()
+    del junk
+    torch.cuda.empty_cache()
+    print("poisoned with", hex(pat), flush=True)
+W = pkg.synth.make_weights(cfg, seed=ws, head_gain=6.0)
+docs = pkg.synth.make_documents(cfg, B, seed=ds, text_len=T, min_words=1)
+args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision="split")
+eng.load_weights(W)
+torch.cuda.synchronize()
+print("forward dump_all", flush=True)
+full = eng.forward(*args, dump_all=True, want_all=True, temperatures=temps, dense_rows=dense)
+torch.cuda.synchronize()
+store = _np(full.all_logits).astype(np.float64)
+conf = fz.softmax64(store / (temps[:, None, None] if temps is not None else 1.0)).max(-1)
+thr = np.full(E1, 2.0)
+active = np.ones(B, dtype=bool)
+for e in range(E1 - 1):
+    c = np.sort(conf[e, active])
+    if len(c) < 2:
+        continue
+    j = int(rng.integers(1, len(c)))
+    thr[e] = 0.5 * (c[j - 1] + c[j])
+    if c[j] - c[j - 1] < 1e-6:
+        thr[e] = 2.0
+    active &= ~(conf[e] > thr[e])
+print("thresholds", thr.tolist(), flush=True)
+for name, kw in (("probe_always", dict(probe_always=True)), ("whole", dict(whole_layers=True)), ("auto", dict()), ("auto2", dict()),
+                 ("xprobe", dict(probe_always=True, xprobe=True))):
+    print("forward", name, flush=True)
+    o = eng.forward(*args, thresholds=thr, temperatures=temps, dense_rows=dense, **kw)
+    torch.cuda.synchronize()
+    eng.check()
+    print("   ok: exits", _np(o.exit_layer).tolist(), "plan", eng.layer_plan(), flush=True)
+eng.close()
+print("case done", flush=True)

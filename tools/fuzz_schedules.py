@@ -1,5 +1,5 @@
 """Randomised cross-check of the exit-layer schedules (GPU box only): for random shapes / exit sets / strategies / thresholds the
-probe-first, whole-layer and automatic schedules and the dump-all rows must agree bit for bit.  Not a test (minutes); run after touching
+probe-first, whole-layer and automatic schedules and the dump-all rows must agree bit for bit, and the X-space probe within tolerance.  Not a test (minutes); run after touching
 the layer loop of csrc/capi.hip:  python tools/fuzz_schedules.py [n_cases]"""
 import importlib
 import os
@@ -60,8 +60,21 @@ def one(case, rng):
     want = _np(full.all_logits)[ex, np.arange(B)]
     ok = all(np.array_equal(o[0], ex) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2]) for o in outs)
     ok = ok and np.array_equal(outs[0][1], want)
+    # the X-space probe (MMEE_FLAG_XPROBE; 12 heads x 768 only, other shapes ignore the flag): a re-association, so a tolerance -- same exits
+    # unless a confidence sits within 1e-5 of its threshold, logits within 1e-4
+    ox = eng.forward(*args, thresholds=thr, temperatures=temps, dense_rows=dense, probe_always=True, xprobe=True)
+    eng.check()
+    exx, lgx = _np(ox.exit_layer), _np(ox.logits)
+    diff = exx != ex
+    near = np.zeros(B, dtype=bool)
+    for e in range(E1 - 1):
+        near |= np.abs(conf[e] - thr[e]) < 1e-5
+    xok = bool((~diff | near).all()) and float(np.abs(lgx[~diff] - outs[0][1][~diff]).max(initial=0.0)) <= 1e-4
+    xrows = eng.layer_plan()["rows_qkv"]
+    ok = ok and xok
     print(f"case {case}: L={L} H={H} exits={ee['exits']} {strat} B={B} T={T} dense={dense} temps={temps is not None} "
-          f"left at {np.bincount(ex, minlength=E1).tolist()} probes {outs[0][3]} auto {outs[3][3]}: {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"left at {np.bincount(ex, minlength=E1).tolist()} probes {outs[0][3]} auto {outs[3][3]} xprobe dlogit "
+          f"{float(np.abs(lgx[~diff] - outs[0][1][~diff]).max(initial=0.0)):.1e} flips {int(diff.sum())} rows_qkv {xrows}: {'ok' if ok else 'MISMATCH'}", flush=True)
     eng.close()
     return ok
 
