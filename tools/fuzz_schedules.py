@@ -1,6 +1,6 @@
 """Randomised cross-check of the exit-layer schedules (GPU box only): for random shapes / exit sets / strategies / thresholds the
 probe-first, whole-layer and automatic schedules and the dump-all rows must agree bit for bit, and the X-space probe within tolerance.  Not a test (minutes); run after touching
-the layer loop of csrc/capi.hip:  python tools/fuzz_schedules.py [n_cases]"""
+the layer loop of csrc/capi.hip:  python tools/fuzz_schedules.py [n_cases [seed]]"""
 import importlib
 import os
 import sys
@@ -24,9 +24,10 @@ def one(case, rng):
     strat = ["ramp", "gate"][int(rng.integers(0, 2))]
     emb = [[], ["vision_avg"], ["text_avg", "text_visual_concat"]][int(rng.integers(0, 3))]
     ee = dict(exits=emb + exits, encoder_layer_strategy=strat)
-    H = [256, 768][int(rng.integers(0, 2))]
-    cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=L, hidden_size=H, intermediate_size=4 * H if H == 768 else 512,
-                               num_attention_heads=H // 64, coordinate_size=40 if H == 256 else 128, shape_size=48 if H == 256 else 128)
+    H = HS[int(rng.integers(0, len(HS)))]
+    cs = {256: (40, 48), 768: (128, 128), 1024: (171, 170)}[H]           # 6 spatial slices: 4 coordinate + 2 shape sizes sum to H
+    cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=L, hidden_size=H, intermediate_size=4 * H if H >= 768 else 512,
+                               num_attention_heads=H // 64, coordinate_size=cs[0], shape_size=cs[1])
     B = int(rng.choice([1, 5, 33, 96]))
     T = int(rng.choice([16, 130, 512]))
     W = pkg.synth.make_weights(cfg, seed=int(rng.integers(1, 1 << 30)), head_gain=6.0)
@@ -79,9 +80,13 @@ def one(case, rng):
     return ok
 
 
+HS = [256, 768]            # third argument "large": also LayoutLMv3-large rows (H = 1024, 16 heads: the X-space probe falls back to K | V)
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "large":
+        HS = [256, 768, 1024]
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
     bad = sum(not one(i, rng) for i in range(n))
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)
