@@ -1004,13 +1004,15 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     // probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document), judged from the
     // stage populations of the last finished forward; no history: probe.  Rates as measured on MI355X; both orders
     // give the same bits, only the time differs.
-    auto probe_pays = [&]() -> bool {
+    // xs: the probe would run in X space (xprobe.hip): it streams the 4 H bytes of a LayerNorm row instead of 8 H of K | V, costs three more
+    // small launches, and a leaving row also skips its Q | K | V projection
+    auto probe_pays = [&](bool xs = false) -> bool {
         if (!prev || prev_B <= 0 || prev[cur].n_rows <= 0) return true;
         const double scale = (double)B / prev_B;
         const double rows = prev[cur].n_rows * scale, leave = (prev[cur].n_rows - prev[cur + 1].n_rows) * scale;
         const double len = (double)prev[cur].sum_len_sq / prev[cur].n_rows;                   // mean keys per query
-        const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I) / 380e12 + 4.0 * len * H / 200e12;
-        const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + 100e-6 + rows * 8.0 * H / 3.6e12;
+        const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I + (xs ? 3.0 * (double)H * H : 0.0)) / 380e12 + 4.0 * len * H / 200e12;
+        const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + (xs ? 180e-6 + rows * 4.0 * H / 4.5e12 : 100e-6 + rows * 8.0 * H / 3.6e12);
         return leave * t_row > 1.1 * cost;
     };
     int next_enc = 0;
@@ -1218,13 +1220,13 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         // probe first: this layer ends in a decision (an exit head, or the final classifier), split attention kernels, no dump of
         // every layer (the dump keeps every document to the end, so nothing would be saved)
         bool probe = probe_on && sp && !no_exit && (exit_here != last);
-        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays();
         bool xspace = false;
         if (probe && (flags & MMEE_FLAG_XPROBE) && use_idx && h->Qc) {
             mmee::XProbeArgs chk{};
             chk.H = H; chk.heads = c.num_attention_heads; chk.bins1 = c.rel_pos_bins; chk.bins2 = c.rel_2d_pos_bins; chk.pair_idx = h->pair_idx;
             xspace = mmee::xprobe_supports(chk, max_len);
         }
+        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays(xspace);
         if (probe && xspace) {
             // decide first, project afterwards: no Q | K | V exists yet
             layer_probe(true);

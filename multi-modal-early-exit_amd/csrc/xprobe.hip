@@ -28,7 +28,6 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 xp_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int XP_THREADS = 512;            // 8 waves
-constexpr int XP_TILE = 16 * 3072;         // 16 split rows of H = 768
 constexpr float kNegBig = -1.0e30f;
 }  // namespace
 
@@ -142,12 +141,19 @@ __device__ __forceinline__ void xp_dma16(unsigned voff, unsigned long long base,
 }
 __device__ __forceinline__ constexpr int xp_sw(int r) { return ((r & 7) << 1) | ((r >> 3) & 1); }
 
-template <int HEADS>      // LayoutLMv3-base: 12 heads, H = 768
+// HEADS x HH = 12 x 768 (LayoutLMv3-base, 3-deep ring) or 16 x 1024 (LayoutLMv3-large: a tile is 64 KB, so the ring is 2 deep: the DMA of
+// tile t + 1 is issued when tile t starts and waited for with vmcnt(0)).
+template <int HEADS, int HH, int RING>
 __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArgs a, const int tstr, const int off_tab, const int off_part, const int off_idx,
                                                                 const int npad) {
     extern __shared__ __attribute__((aligned(1024))) char xsm[];
-    constexpr int H = 768, NW = XP_THREADS / 64, ROWB = H * 4;
-    static_assert(NW == 8 && (H / 32) % NW == 0 && H / 16 == 6 * NW, "k-steps and column groups are divided over eight waves");
+    constexpr int H = HH, NW = XP_THREADS / 64, ROWB = H * 4, XP_TILE = 16 * ROWB;
+    constexpr int KSW = H / 32 / NW;          // k-steps of the scores per wave (3 / 4)
+    constexpr int CGW = H / 16 / NW;          // 16-column groups of the weighted sums per wave (6 / 8)
+    constexpr int PPR = ROWB / 1024;          // 1-KiB DMA pieces per tile row (3 / 4)
+    constexpr int PIECES = 2 * PPR;           // pieces per wave and tile: two rows (6 / 8)
+    static_assert(NW == 8 && KSW * NW * 32 == H && CGW * NW * 16 == H && HEADS * 64 == H && HEADS <= 16, "k-steps and column groups are divided over eight waves");
+    static_assert((RING == 2 || RING == 3) && (PIECES == 6 || PIECES == 8), "ring depth / wait immediates");
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)xsm;
     const int n_docs = a.counts->n_docs, heads = a.heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,10 +178,10 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
         const unsigned* slab = a.pair_idx + (size_t)a.doc_orig[d] * a.idx_doc_stride;      // query block 0 of the document
         const int n_rt = (len + 15) >> 4;
         auto issue_tile = [&](int rt) __attribute__((always_inline)) {
-            const int buf = rt % 3;
+            const int buf = rt % RING;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int row = 2 * wave + i / 3, pc = i % 3;
+            for (int i = 0; i < PIECES; ++i) {
+                const int row = 2 * wave + i / PPR, pc = i % PPR;
                 int src = rt * 16 + row;
                 src = src < len ? src : len - 1;                   // rows past the end: a copy of the last row, weighted with p = 0
                 const unsigned long long base = xp_sgpr64((unsigned long long)(size_t)(x0 + (size_t)src * ROWB + pc * 1024));
@@ -183,9 +189,9 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
             }
         };
         issue_tile(0);
-        if (n_rt > 1) issue_tile(1);
+        if (RING == 3 && n_rt > 1) issue_tile(1);
         // ---- a. the u fragments of the wave's three k-steps as split-f16 planes (scale of xprobe_u_kernel: max |s u| in [2^12, 2^13)) ----
-        f16x8 bh[3], bl[3];
+        f16x8 bh[KSW], bl[KSW];
         float inv, s0;
         {
             const float us = a.s0[((size_t)d * heads + mh) * 2 + 1];
@@ -193,9 +199,9 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
             s0 = a.s0[((size_t)d * heads + mh) * 2] * kL2e;
             const float* ur = a.u + ((size_t)d * heads + mh) * H + 8 * kq;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const f32x4 u0 = *reinterpret_cast<const f32x4*>(ur + 32 * (3 * wave + i));
-                const f32x4 u1 = *reinterpret_cast<const f32x4*>(ur + 32 * (3 * wave + i) + 4);
+            for (int i = 0; i < KSW; ++i) {
+                const f32x4 u0 = *reinterpret_cast<const f32x4*>(ur + 32 * (KSW * wave + i));
+                const f32x4 u1 = *reinterpret_cast<const f32x4*>(ur + 32 * (KSW * wave + i) + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float v = (e < 4 ? u0[e] : u1[e - 4]) * us;
@@ -227,27 +233,31 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
             iby[j] = (unsigned char)(w >> 22);
         }
         // ---- d. the tiles ----
-        f32x4 cacc[6];
+        f32x4 cacc[CGW];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < CGW; ++i) cacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         float m_run = kNegBig, l_run = 0.f;                        // of head m; l over this lane's rows 4 kq + r of every tile
         const float* th = tab + (m < heads ? m : 0) * tstr;
         const int swm = xp_sw(m);                                  // row reads: lane <-> tile row m
         const int rowt = 4 * kq + (m >> 2), swt = xp_sw(rowt);     // transposed reads: lane 4 q + p of group kq supplies row 4 kq + q, columns 4 p ..
         for (int rt = 0; rt < n_rt; ++rt) {
-            const int buf = rt % 3;
-            if (rt + 1 < n_rt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // this wave's pieces of tile rt have landed (tile rt + 1 may fly)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int buf = rt % RING;
+            if (RING == 3 && rt + 1 < n_rt) {                      // this wave's pieces of tile rt have landed (tile rt + 1 may fly)
+                if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __syncthreads();                                        // ... and everybody's; tile rt - 1 is no longer read
-            if (rt + 2 < n_rt) issue_tile(rt + 2);
+            if (rt + RING - 1 < n_rt) issue_tile(rt + RING - 1);
             const char* tile = xsm + buf * XP_TILE;
             // partial scores of the wave's three k-steps
             {
                 const char* pa = tile + m * ROWB;
                 f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int c = 8 * (3 * wave + i) + 4 * (kq >> 1) + (kq & 1);       // 16-byte chunk of the hi plane; lo two chunks on
+                for (int i = 0; i < KSW; ++i) {
+                    const int c = 8 * (KSW * wave + i) + 4 * (kq >> 1) + (kq & 1);     // 16-byte chunk of the hi plane; lo two chunks on
                     const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + 16 * (c ^ swm));
                     const f16x8 al = *reinterpret_cast<const f16x8*>(pa + 16 * ((c + 2) ^ swm));
                     ps = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[i], ps, 0, 0, 0);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
                 for (int r = 0; r < 4; ++r) {
                     const float f = __shfl(alpha, 4 * kq + r, 64);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) cacc[i][r] *= f;
+                    for (int i = 0; i < CGW; ++i) cacc[i][r] *= f;
                 }
             }
             f16x4 p_hi, p_lo;
@@ -299,8 +309,8 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
             // weighted sums: D[head][col] += P^T[head][row] X[row][col]; 16-lane group kq takes rows 4 kq .. 4 kq + 3 of the 16 columns
             const unsigned tb = lds0 + (unsigned)(buf * XP_TILE + rowt * ROWB + 8 * (m & 1));
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int c = 4 * (6 * wave + i) + ((m >> 1) & 1);                 // chunk of columns 16 g + 4 p .. (hi); lo two chunks on
+            for (int i = 0; i < CGW; ++i) {
+                const int c = 4 * (CGW * wave + i) + ((m >> 1) & 1);               // chunk of columns 16 g + 4 p .. (hi); lo two chunks on
                 const unsigned ah = tb + 16u * (unsigned)(c ^ swt), al = tb + 16u * (unsigned)((c + 2) ^ swt);
                 const f16x4 xh = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) xp_h4*)(size_t)ah));
                 const f16x4 xl = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) xp_h4*)(size_t)al));
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
             if (h < heads) {
                 const float f = a.xs_inv / lh;                     // the 2^10 of p cancels in c / l
 #pragma unroll
-                for (int i = 0; i < 6; ++i) a.cvec[((size_t)d * heads + h) * H + (6 * wave + i) * 16 + m] = cacc[i][r] * f;
+                for (int i = 0; i < CGW; ++i) a.cvec[((size_t)d * heads + h) * H + (CGW * wave + i) * 16 + m] = cacc[i][r] * f;
             }
         };
         store_head(std::integral_constant<int, 0>{});
@@ -337,8 +347,9 @@ __global__ __launch_bounds__(XP_THREADS) void xprobe_attn_kernel(const XProbeArg
 // three terms per product as everywhere.  grid (heads, ceil(max_docs / 64)), 4 waves.  (The first version walked the f32 weights with
 // VALU dot products, 8 documents per workgroup: 122 us at 1024 documents against 27 for this one.)
 // ---------------------------------------------------------------------------------------------------------------
+template <int HH>
 __global__ __launch_bounds__(256) void xprobe_v_kernel(const XProbeArgs a) {
-    constexpr int H = 768;                                         // xprobe_supports
+    constexpr int H = HH;                                          // xprobe_supports: 768 or 1024
     const int n_docs = a.counts->n_docs;
     const int h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d0 = (blockIdx.y * 4 + wave) * 16;
@@ -398,31 +409,51 @@ __global__ __launch_bounds__(256) void xprobe_v_kernel(const XProbeArgs a) {
     split_flag_overflow(amax, a.err_flag);
 }
 
+namespace {
+struct XpLayout { int tstr, off_tab, off_part, off_idx, npad, lds; };
+XpLayout xp_layout(const XProbeArgs& a, int max_len) {
+    XpLayout L;
+    const int ring = a.H == 768 ? 3 : 2;
+    L.tstr = a.bins1 + 1 + 2 * a.bins2;
+    L.npad = (max_len + 15) & ~15;
+    L.off_tab = ring * 16 * a.H * 4;
+    L.off_part = (L.off_tab + a.heads * L.tstr * 4 + 15) & ~15;
+    L.off_idx = L.off_part + 8 * 4 * a.heads * 16;
+    L.lds = L.off_idx + 3 * L.npad + 16;
+    return L;
+}
+}  // namespace
+
 bool xprobe_supports(const XProbeArgs& a, int max_len) {
-    // built for 12 heads x 768 columns (LayoutLMv3-base: eight waves share 24 k-steps and 48 column groups); wider models run the probe of
-    // attention_idx.hip
-    const int tstr = a.bins1 + 1 + 2 * a.bins2;
-    const int lds = 3 * XP_TILE + ((12 * tstr * 4 + 15) & ~15) + 8 * 4 * 12 * 16 + 3 * ((max_len + 15) & ~15) + 16;
-    return a.H == 768 && a.heads == 12 && a.pair_idx != nullptr && a.bins1 <= 255 && a.bins2 <= 255 && lds <= 160 * 1024;
+    // built for 12 heads x 768 columns (LayoutLMv3-base) and 16 x 1024 (LayoutLMv3-large): eight waves share H / 32 k-steps and H / 16
+    // column groups; other models run the probe of attention_idx.hip
+    const bool shape = (a.H == 768 && a.heads == 12) || (a.H == 1024 && a.heads == 16);
+    return shape && a.pair_idx != nullptr && a.bins1 <= 255 && a.bins2 <= 255 && xp_layout(a, max_len).lds <= 160 * 1024;
+}
+
+template <int HEADS, int HH, int RING>
+static void launch_xprobe_attn(const XProbeArgs& a, const XpLayout& L, int grid, hipStream_t s) {
+    static int attr_lds = 0;
+    if (L.lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xprobe_attn_kernel<HEADS, HH, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
+        attr_lds = L.lds;
+    }
+    hipLaunchKernelGGL((xprobe_attn_kernel<HEADS, HH, RING>), dim3(grid), dim3(XP_THREADS), L.lds, s, a, L.tstr, L.off_tab, L.off_part, L.off_idx, L.npad);
 }
 
 void launch_xprobe(const XProbeArgs& a, int max_docs, int max_len, int num_cus, hipStream_t s) {
     const int groups = (max_docs + 7) / 8;
     hipLaunchKernelGGL(xprobe_u_kernel, dim3(a.heads, groups), dim3(256), 0, s, a);
-    const int tstr = a.bins1 + 1 + 2 * a.bins2, npad = (max_len + 15) & ~15;
-    const int off_tab = 3 * XP_TILE;
-    const int off_part = (off_tab + 12 * tstr * 4 + 15) & ~15;
-    const int off_idx = off_part + 8 * 4 * 12 * 16;
-    const int lds = off_idx + 3 * npad + 16;
-    static int attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xprobe_attn_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
-    }
+    const XpLayout L = xp_layout(a, max_len);
     int grid = max_docs < num_cus ? max_docs : num_cus;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((xprobe_attn_kernel<12>), dim3(grid), dim3(XP_THREADS), lds, s, a, tstr, off_tab, off_part, off_idx, npad);
-    hipLaunchKernelGGL(xprobe_v_kernel, dim3(a.heads, (max_docs + 63) / 64), dim3(256), 0, s, a);
+    if (a.H == 768) {
+        launch_xprobe_attn<12, 768, 3>(a, L, grid, s);
+        hipLaunchKernelGGL(xprobe_v_kernel<768>, dim3(a.heads, (max_docs + 63) / 64), dim3(256), 0, s, a);
+    } else {
+        launch_xprobe_attn<16, 1024, 2>(a, L, grid, s);
+        hipLaunchKernelGGL(xprobe_v_kernel<1024>, dim3(a.heads, (max_docs + 63) / 64), dim3(256), 0, s, a);
+    }
 }
 
 }  // namespace mmee

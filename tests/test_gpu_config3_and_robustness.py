@@ -84,6 +84,12 @@ def test_config3_full_size_against_cpu_restatement(pkg, oracle):
     assert np.array_equal(_np(out.exit_layer), ex), (_np(out.exit_layer), ex)
     # the policy's `predictions` are rows of the temperature-scaled store (EE/eval.py:321-323 scales, EE/policy.py:36 picks)
     np.testing.assert_allclose(_np(out.logits), pred, rtol=0, atol=LOGIT_TOL)
+    # the X-space probe on the 16-head x 1024 instantiation (csrc/xprobe.hip): same exits, same tolerance against the CPU restatement
+    outx = eng.forward(*args, thresholds=thr, temperatures=temps, xprobe=True, probe_always=True, validate=True)
+    assert np.array_equal(_np(outx.exit_layer), ex)
+    np.testing.assert_allclose(_np(outx.logits), pred, rtol=0, atol=LOGIT_TOL)
+    plan = eng.layer_plan()
+    assert sum(plan["docs_probe"]) > 0 and plan["rows_qkv"][-1] == 0        # probed, and the last layer projected nothing
     eng.close()
 
 
@@ -118,6 +124,17 @@ def test_config3_full_size_properties(pkg, oracle):
     perm = np.random.default_rng(3).permutation(B)
     outp = eng.forward(*(a[perm] for a in args), thresholds=thr, temperatures=temps)
     assert np.array_equal(_np(outp.exit_layer), ex[perm]) and np.array_equal(_np(outp.logits), got[perm])
+    # X-space probe at every one of the 23 exit layers: a re-association, so exits equal (thresholds sit in gaps) and logits within tolerance
+    outx = eng.forward(*args, thresholds=thr, temperatures=temps, xprobe=True, probe_always=True, validate=True)
+    exx = _np(outx.exit_layer)
+    near = np.zeros(B, dtype=bool)
+    for e in range(len(thr) - 1):
+        near |= np.abs(conf[e] - thr[e]) < 1e-5
+    assert (exx == ex)[~near].all()
+    same = exx == ex
+    np.testing.assert_allclose(_np(outx.logits)[same], got[same], rtol=0, atol=LOGIT_TOL)
+    planx = eng.layer_plan()
+    assert sum(planx["docs_probe"]) > 0 and planx["rows_qkv"][-1] == 0 and all(q <= m for q, m in zip(planx["rows_qkv"][1:], planx["rows_main"][:-1]))
     eng.close()
 
 
