@@ -10,13 +10,15 @@
 // instead of 6 KB of K | V, and no Q | K | V projection has to exist yet: the layer's Q | K | V GEMM then runs for the documents that STAY
 // only, and not at all in the last layer.  Four small launches:
 //   1. Q of the CLS rows: the split GEMM on one row per document (capi.hip; W_q is the first third of the fused Q | K | V weight),
-//   2. xprobe_u_kernel     u[d][h][:] = W_k,h^T q[d][h], s0[d][h] = q . b_k         (weights streamed once per 8 documents),
-//   3. xprobe_attn_kernel  one workgroup per document; its rows cross HBM -> LDS once (LDS-DMA, 16-row tiles, double buffer): scores
-//                          against the 12 heads' u on the f16 matrix cores (x rows ARE split-f16 planes; u is split in LDS with a
-//                          per-head power-of-two scale) + q . b_k + relative-position bias of query 0 from the pair index
-//                          (attention_idx.hip) -> online softmax -> c += P^T X on the matrix cores from the same LDS tile,
-//   4. xprobe_v_kernel     ctx[d][h] = W_v,h c[d][h] + b_v  -> the document's context row as split planes, where the probe's
-//                          attention-output GEMM expects it.
+//   2. xprobe_u_kernel     u[d][h][:] = W_k,h^T q[d][h], s0[d][h] = q . b_k, the power-of-two plane scale of u, and the documents'
+//                          order by falling length (weights streamed once per 8 documents),
+//   3. xprobe_attn_kernel  one workgroup per document, longest first; its rows cross HBM -> LDS once (LDS-DMA, 16-row tiles, ring of
+//                          3 / 2): scores against the heads' u on the f16 matrix cores (x rows ARE split-f16 planes; u is split in
+//                          registers) + q . b_k + relative-position bias of query 0 from the pair index (attention_idx.hip) -> online
+//                          softmax -> c += P^T X on the matrix cores from the same LDS tile,
+//   4. xprobe_v_kernel     ctx[d][h] = W_v,h c[d][h] + b_v on the matrix cores -> the document's context row as split planes, where
+//                          the probe's attention-output GEMM expects it.
+// Shapes: 12 heads x 768 (LayoutLMv3-base) and 16 x 1024 (-large); xprobe_supports() says no to everything else.
 // The result is a re-association of the whole-layer arithmetic (~1e-6 apart, inside the 1e-4 bar): with this flag "early exit == dump-all
 // row bit for bit" holds to tolerance, not to the bit; MMEE_FLAG_WHOLE_LAYERS and the default probe stay bit-identical to each other.
 #include <type_traits>
