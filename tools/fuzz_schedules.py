@@ -18,18 +18,21 @@ def softmax64(x):
     return e / e.sum(-1, keepdims=True)
 
 
+BIG = False                # fourth argument "big": bench-sized cases (L = 12, H = 768, hundreds of ragged documents of up to 512 tokens)
+
+
 def one(case, rng):
-    L = int(rng.integers(2, 6))
+    L = 12 if BIG else int(rng.integers(2, 6))
     exits = sorted(rng.choice(np.arange(1, L + 1), size=int(rng.integers(1, L + 1)), replace=False).tolist())
     strat = ["ramp", "gate"][int(rng.integers(0, 2))]
     emb = [[], ["vision_avg"], ["text_avg", "text_visual_concat"]][int(rng.integers(0, 3))]
     ee = dict(exits=emb + exits, encoder_layer_strategy=strat)
-    H = HS[int(rng.integers(0, len(HS)))]
+    H = 768 if BIG else HS[int(rng.integers(0, len(HS)))]
     cs = {256: (40, 48), 768: (128, 128), 1024: (171, 170)}[H]           # 6 spatial slices: 4 coordinate + 2 shape sizes sum to H
     cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=L, hidden_size=H, intermediate_size=4 * H if H >= 768 else 512,
                                num_attention_heads=H // 64, coordinate_size=cs[0], shape_size=cs[1])
-    B = int(rng.choice([1, 5, 33, 96]))
-    T = int(rng.choice([16, 130, 512]))
+    B = int(rng.choice([100, 300, 512] if BIG else [1, 5, 33, 96]))
+    T = 512 if BIG else int(rng.choice([16, 130, 512]))
     W = pkg.synth.make_weights(cfg, seed=int(rng.integers(1, 1 << 30)), head_gain=6.0)
     docs = pkg.synth.make_documents(cfg, B, seed=int(rng.integers(1, 1 << 30)), text_len=T, min_words=1)
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
@@ -85,6 +88,8 @@ HS = [256, 768]            # third argument "large": also LayoutLMv3-large rows 
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "large":
         HS = [256, 768, 1024]
+    if len(sys.argv) > 3 and sys.argv[3] == "big":
+        BIG = True
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
     bad = sum(not one(i, rng) for i in range(n))
