@@ -189,6 +189,26 @@ __device__ __forceinline__ void store_split4(void* row_base, int col, const f32x
     *reinterpret_cast<f16x4*>(p) = hi;
     *reinterpret_cast<f16x4*>(p + 32) = lo;
 }
+// The same row piece, stored as ONE contiguous 16 bytes per lane: lanes 4i .. 4i+3 of a wave hold the 16 columns of one 64-byte group
+// (col = 4 * lane + const), so a quad-permute hands lane 4i the group's hi[0..7], 4i+1 hi[8..15], 4i+2 lo[0..7], 4i+3 lo[8..15]: a wave's
+// store instruction then writes whole contiguous kilobytes instead of 8-byte pieces 32 bytes apart (the GEMM epilogue's form).  All four
+// lanes of a quad must be active and col must be 4 * lane + a multiple of 16.
+__device__ __forceinline__ void store_split4_quad(void* row_base, int col, const f32x4& v, float scale, float& amax, int lane) {
+    f16x4 hi, lo;
+    split_f16x4(v, scale, hi, lo, amax);
+    const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
+    const bool take_lo = (lane & 2) != 0;
+    const int a0 = __builtin_amdgcn_mov_dpp(h2.x, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp(h2.y, 0x88, 0xf, 0xf, true);
+    const int b0 = __builtin_amdgcn_mov_dpp(l2.x, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp(l2.y, 0x88, 0xf, 0xf, true);
+    const int c0 = __builtin_amdgcn_mov_dpp(h2.x, 0xDD, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp(h2.y, 0xDD, 0xf, 0xf, true);
+    const int d0 = __builtin_amdgcn_mov_dpp(l2.x, 0xDD, 0xf, 0xf, true), d1 = __builtin_amdgcn_mov_dpp(l2.y, 0xDD, 0xf, 0xf, true);
+    int4 piece;
+    piece.x = take_lo ? b0 : a0;
+    piece.y = take_lo ? b1 : a1;
+    piece.z = take_lo ? d0 : c0;
+    piece.w = take_lo ? d1 : c1;
+    *reinterpret_cast<int4*>(reinterpret_cast<char*>(row_base) + (size_t)(col >> 4) * 64 + (lane & 3) * 16) = piece;
+}
 // 4 consecutive columns [col, col+4) of a split row back to f32: (hi + lo) * inv_scale — exact: hi + lo carries <= 23 significant bits
 __device__ __forceinline__ f32x4 load_split4(const void* row_base, int col, float inv_scale) {
     const char* p = reinterpret_cast<const char*>(row_base) + (col >> 4) * 64 + (col & 15) * 2;

@@ -175,7 +175,7 @@ __device__ __forceinline__ void wave_store_row_split(void* dst_row, const f32x4 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) store_split4(dst_row, c, x[i], scale, amax);
+        if (c < H) store_split4_quad(dst_row, c, x[i], scale, amax, lane);      // split rows exist only where H % 256 == 0: whole waves take the branch
     }
 }
 
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < H) store_split4(dst_split + (size_t)r * H * 4, c, x[i], split_scale, amax);
+                if (c < H) store_split4_quad(dst_split + (size_t)r * H * 4, c, x[i], split_scale, amax, lane);
             }
         }
     }
