@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void patch_split_kernel(const float* __restric
         const int c = k / (P * P), rem = k - c * P * P;
         const int py = rem / P, px = rem - py * P;
         const f32x4 v = *reinterpret_cast<const f32x4*>(pix + (((size_t)b * C + c) * R + (size_t)(gy * P + py)) * R + gx * P + px);
-        store_split4(dst + r * (size_t)K * 4, k, v, scale, amax);
+        store_split4_quad(dst + r * (size_t)K * 4, k, v, scale, amax, threadIdx.x & 63);      // K % 16 == 0: a quad of lanes = one 64-byte group
     }
     split_flag_overflow(amax, err_flag);
 }
