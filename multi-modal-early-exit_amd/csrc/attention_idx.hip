@@ -171,7 +171,9 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // 10.5 ms, eight precomputed V fragment addresses 10.0 ms, software-pipelined tiles (Q K^T of tile kt + 1 paired with the exp / split of
 // tile kt, P V of tile kt with the lookups of tile kt + 1, in one basic block each) 10.1 ms at 168 VGPRs + 18 spilled, K / V DMA and Q
 // loads ahead of the table fill with no drain in front 9.9 ms (no change), the next queue ticket drawn at the start of an item 10.4 ms
-// (a held ticket starts late: the queue balances worse).
+// (a held ticket starts late: the queue balances worse), six waves per workgroup (192 queries per item, two workgroups per CU, waves 4 and 5
+// issue no DMA: correct, but 13.8 ms -- a workgroup's six waves land 2, 2, 1, 1 on the four SIMDs and a second workgroup of 168-VGPR waves
+// does not fit beside it, so a CU runs six waves instead of twelve).
 constexpr int kXP = 2;
 template <int MODE, bool BIAS, int XP>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
