@@ -315,6 +315,38 @@ def test_small_split_precision_every_exit_kind_vs_oracle(pkg, oracle, strategy):
     eng.close()
 
 
+@pytest.mark.parametrize("bins", [(32, 128), (128, 64)])
+def test_wide_bucket_tables_run_the_delta_table_attention(pkg, oracle, bins):
+    """Bucket tables beyond 64 bins do not fit the pair index (6-bit fields): the split precision then runs csrc/attention_pair.hip (clamped
+    Delta tables gathered per layer and head) -- a PRODUCT kernel that no other test reaches.  Same checks as the test above:
+    relative_position_bucket with num_buckets = 128 (HF:392-413), dump-all and early exit against the live oracle, both row layouts."""
+    ee = dict(exits=["text_visual_concat", 1, 2, 3], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                               coordinate_size=48, shape_size=32, rel_pos_bins=bins[0], rel_2d_pos_bins=bins[1])
+    W = pkg.synth.make_weights(cfg, seed=22)
+    docs = pkg.synth.make_documents(cfg, 6, seed=6, text_len=40, min_words=2)
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], strategy="ramp", return_hidden_cls=True)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40, precision="split")
+    assert eng.precision == "split"
+    eng.load_weights(W)
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    out = eng.forward(*args, dump_all=True, want_all=True, want_hidden_cls=True, validate=True)
+    np.testing.assert_allclose(_np(out.hidden_cls), ref["hidden_cls"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(_np(out.all_logits), ref["logits_store"], rtol=0, atol=LOGIT_TOL)
+    conf = oracle.softmax64(ref["logits_store"]).max(-1)
+    srt = np.sort(conf.ravel())
+    k = int(np.argmax(np.diff(srt)[len(srt) // 4: 3 * len(srt) // 4])) + len(srt) // 4
+    thr = 0.5 * (srt[k] + srt[k + 1])
+    assert np.abs(conf - thr).min() > 1e-5
+    ex, pred, _ = oracle.policy_scan(ref["logits_store"], thr)
+    for dense in (False, True):
+        for kw in (dict(), dict(whole_layers=True), dict(probe_always=True)):
+            o2 = eng.forward(*args, thresholds=thr, dense_rows=dense, validate=True, **kw)
+            assert np.array_equal(_np(o2.exit_layer), ex)
+            np.testing.assert_allclose(_np(o2.logits), pred, rtol=0, atol=LOGIT_TOL)
+    eng.close()
+
+
 @pytest.mark.parametrize("precision", ["split", "fp32"])
 def test_bench_size_early_exit_properties(pkg, oracle, precision):
     """BASELINE configs[1] shape (base, exits 2/4/6/8/10 + final, T = 512, ragged documents) at a size no CPU oracle
