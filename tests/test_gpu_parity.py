@@ -594,9 +594,10 @@ def test_baseline_config1_64_documents_threshold_sweep(pkg, oracle):
         if 0.0 < thr < 1.0 and np.abs(conf[:-1] - thr).min() < 2e-5:    # ill-posed: a confidence sits on the threshold
             continue
         ex, pred, _ = oracle.policy_scan(store, thr)
-        out = eng.forward(*args, thresholds=thr)
-        assert np.array_equal(_np(out.exit_layer), ex), thr
-        np.testing.assert_allclose(_np(out.logits), pred, rtol=0, atol=LOGIT_TOL)
+        for kw in (dict(), dict(xprobe=True, probe_always=True)):         # the K | V probe and the X-space probe (MMEE_FLAG_XPROBE)
+            out = eng.forward(*args, thresholds=thr, **kw)
+            assert np.array_equal(_np(out.exit_layer), ex), (thr, kw)
+            np.testing.assert_allclose(_np(out.logits), pred, rtol=0, atol=LOGIT_TOL)
         checked += 1
     assert checked >= 5
     eng.close()
