@@ -80,7 +80,7 @@ struct ee_handle {
     // CLS probe (probe-first layers): one row per active document
     float *Yc = nullptr, *Ycs = nullptr, *H1c = nullptr, *Xc = nullptr, *Xcs = nullptr;
     int* xp_order = nullptr;                      // [max_docs + 1]: documents by falling length, ticket counter
-    float *Qc = nullptr, *xp_u = nullptr, *xp_s0 = nullptr, *xp_c = nullptr;      // X-space probe (xprobe.hip): CLS queries, u, q.b_k, weighted row sums
+    float *Qc = nullptr, *xp_u = nullptr, *xp_s0 = nullptr, *xp_c = nullptr, *xp_part = nullptr;      // X-space probe (xprobe.hip): CLS queries, u, q.b_k, weighted row sums
     std::vector<int> layer_xprobe;                // 1: the layer's probe ran in X space
     int* iota = nullptr;                          // 0 .. max_docs-1
     float *X, *Y, *QKV, *CTX, *H1, *vis_raw, *text_part, *vis_part, *cat_part, *pooled[3], *hid, *hid2, *head_logits, *pol_logits;
@@ -512,6 +512,7 @@ int ee_create(const ee_config* c, ee_handle** out) {
                     rc |= dev_alloc(h, &h->xp_s0, Bm * (size_t)c->num_attention_heads * 2);
                     rc |= dev_alloc(h, &h->xp_order, Bm + 1);
                     rc |= dev_alloc(h, &h->xp_c, Bm * (size_t)c->num_attention_heads * H);
+                    rc |= dev_alloc(h, &h->xp_part, 4 * Bm * H);      // split-K parts of the probe's FFN-down rows
                 }
                 if (!rc) {
                     std::vector<int> io(Bm);
@@ -1206,11 +1207,23 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             g.alpha = w.f1_inv / mmee::kSplitScaleX; g.out_split = 1; g.out_scale = mmee::kSplitScaleH1;
             launch_gemm_split(g, EPI_GELU, B, cus, s);
             g = GemmArgs{};
-            g.A = h->H1c; g.lda = I; g.W = w.f2_s; g.bias = w.f2_b; g.C = h->Xc; g.ldc = H; g.resid = h->Ycs; g.ldr = H;
-            g.resid_split_inv = 1.0f / mmee::kSplitScaleX; g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.probe = 1;
-            g.m_ptr = nd; g.N = H; g.K = I; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
-            launch_gemm_split(g, EPI_RESID, B, cus, s);
-            launch_ln_rows(h->Xc, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Xcs, mmee::kSplitScaleX, h->err_flag);
+            constexpr int kSplitK = 4;
+            if (xspace && h->xp_part && (I / 32) % kSplitK == 0) {
+                // X space (already a re-association of the whole-layer arithmetic): the 96-stage k-loop of this one-row-per-document GEMM
+                // is divided over four workgroups per tile; the LayerNorm kernel adds the four parts in order, the bias and the residual
+                g.A = h->H1c; g.lda = I; g.W = w.f2_s; g.C = h->xp_part; g.ldc = H; g.k_splits = kSplitK; g.split_stride = (size_t)B * H;
+                g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.probe = 1;
+                g.m_ptr = nd; g.N = H; g.K = I; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+                launch_gemm_split(g, EPI_BIAS, B, cus, s);
+                launch_ln_rows(h->xp_part, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Xcs, mmee::kSplitScaleX, h->err_flag,
+                               kSplitK, (size_t)B * H, w.f2_b, h->Ycs, 1.0f / mmee::kSplitScaleX);
+            } else {
+                g.A = h->H1c; g.lda = I; g.W = w.f2_s; g.bias = w.f2_b; g.C = h->Xc; g.ldc = H; g.resid = h->Ycs; g.ldr = H;
+                g.resid_split_inv = 1.0f / mmee::kSplitScaleX; g.alpha = w.f2_inv / mmee::kSplitScaleH1; g.probe = 1;
+                g.m_ptr = nd; g.N = H; g.K = I; g.scale = 1.f; g.prio_mode = 1; g.err_flag = h->err_flag;
+                launch_gemm_split(g, EPI_RESID, B, cus, s);
+                launch_ln_rows(h->Xc, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Xcs, mmee::kSplitScaleX, h->err_flag);
+            }
             launch_gather_cls(h->Xcs, H, h->iota, nullptr, nd, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
             h->layer_probe_stage[l] = cur;
         };

@@ -182,7 +182,7 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
 // per wave where 2 KB are free.
 template <int EPI, bool OUT_SPLIT, int WN, int RB>
 __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* smem, f32x4 (&acc)[4][4], int m0, int n0, int M,
-                                                   int wave, int lane, const f32x4 bv, const f32x4 lam) {
+                                                   int wave, int lane, const f32x4 bv, const f32x4 lam, const size_t c_shift = 0) {
     const int wr = wave / WN, wc = wave % WN;
     const int l15 = lane & 15, gq = lane >> 4;
     float* stg = smem + wave * (RB * 64);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
                     if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
                     else v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
                 }
-                if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
+                if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + c_shift + (size_t)row * g.ldc + col) = v;
             }
             if (OUT_SPLIT) {
                 f16x4 hi, lo;
@@ -260,8 +260,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     const int M = g.m_ptr ? *g.m_ptr : g.m_static;
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = g.N / BN;
-    const int n_tiles = tiles_m * tiles_n;
-    const int nk = g.K / Cfg::KSTAGE;
+    // split-K (the CLS-probe launches, TAG 1, only): K is divided over k_splits workgroups per tile, part p goes to C + p * split_stride
+    constexpr bool KSPLIT = TAG == 1;
+    const int ksp = KSPLIT && g.k_splits > 1 ? g.k_splits : 1;
+    const int n_tiles = tiles_m * tiles_n * ksp;
+    const int nk = g.K / Cfg::KSTAGE / ksp;
+    int ks_pop = 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
@@ -332,8 +336,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             return false;
         }
         if (tile >= n_tiles) return false;
-        tm = tile / tiles_n;
-        tn = tile - tm * tiles_n;
+        int t2 = tile;
+        if (KSPLIT) { t2 = tile / ksp; ks_pop = tile - t2 * ksp; }
+        tm = t2 / tiles_n;
+        tn = t2 - tm * tiles_n;
         tile += gridDim.x;
         return true;
     };
@@ -342,12 +348,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     // Wave w owns A pieces w, w + NW, ... and W pieces likewise.
     struct TileCtx {
         int m0, n0;
+        int kt0;                                     // split-K: first k-stage of this workgroup's part
         unsigned a_voff[PA], w_voff[PW];
         unsigned long long a_base, w_base;
     };
     auto setup = [&](int tm, int tn, TileCtx& t) __attribute__((always_inline)) {
         t.m0 = __builtin_amdgcn_readfirstlane(tm * BM);
         t.n0 = __builtin_amdgcn_readfirstlane(tn * BN);
+        t.kt0 = KSPLIT ? __builtin_amdgcn_readfirstlane(ks_pop * nk) : 0;
         const int first = g.row_src ? g.row_src[t.m0] : t.m0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                    (unsigned)__builtin_amdgcn_readfirstlane((int)(w_base_v & 0xffffffffu));
     };
     auto issue = [&](const TileCtx& t, int kt, int buf) __attribute__((always_inline)) {
-        const unsigned long long koff = (unsigned long long)kt * (unsigned)ROWB;
+        const unsigned long long koff = (unsigned long long)(kt + (KSPLIT ? t.kt0 : 0)) * (unsigned)ROWB;
         const unsigned dst = lds0 + (unsigned)buf * STAGE_BYTES + (unsigned)wave * 1024u;
 #pragma unroll
         for (int j = 0; j < PA; ++j) dma_piece(t.a_voff[j], t.a_base + koff, dst + (unsigned)(Cfg::NW * j) * 1024u);
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     if (NST >= 4 && nk > 2) issue(cur, 2, 2);
     for (;;) {
         const int m0 = cur.m0, n0 = cur.n0;
+        const size_t c_shift = KSPLIT && ksp > 1 ? (size_t)(cur.kt0 / nk) * g.split_stride : 0;
         f32x16 acc[2][2];
         f32x4 acc16[4][4];
         if constexpr (Cfg::MF == 32) {
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 if constexpr (HANDOVER)
                     split_store_tile16<EPI, OUT_SPLIT, WN, 16>(g, smem + last_slot * (STAGE_BYTES / 4), acc16, m0, n0, M, wave, lane, bv, lam);
                 else
-                    split_store_tile16<EPI, OUT_SPLIT, WN, 32>(g, smem, acc16, m0, n0, M, wave, lane, bv, lam);
+                    split_store_tile16<EPI, OUT_SPLIT, WN, 32>(g, smem, acc16, m0, n0, M, wave, lane, bv, lam, c_shift);
             } else {
                 split_store_tile<EPI, OUT_SPLIT, WN>(g, smem, acc, m0, n0, M, wave, lane);
             }
@@ -532,7 +541,7 @@ static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStrea
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int tiles = ((max_m + Cfg::BM - 1) / Cfg::BM) * (a.N / Cfg::BN);
+    const int tiles = ((max_m + Cfg::BM - 1) / Cfg::BM) * (a.N / Cfg::BN) * (TAG == 1 && a.k_splits > 1 ? a.k_splits : 1);
     int grid = Cfg::WGS * num_cus;
     if (grid > tiles) grid = tiles;
     if (grid < 1) grid = 1;

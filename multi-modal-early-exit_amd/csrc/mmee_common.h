@@ -248,6 +248,8 @@ struct GemmArgs {
     int scale_cols;              // columns [0, scale_cols) are multiplied by `scale` after the bias (Q / sqrt(d))
     float scale;
     const float* col_scale;      // optional per-column factor applied to (acc + bias) before the residual (BEiT lambda_1/2)
+    int k_splits;                // CLS-probe launches of the split kernel only (probe = 1): > 1 divides K over that many workgroups per tile; part p is
+    size_t split_stride;         //   written (bias epilogue, f32) at C + p * split_stride; the LayerNorm kernel that follows adds the parts in order
     // AMODE_IM2COL: A row (b, p) = patch p of image b, k = (c, ky, kx)   (Conv2d k = s = patch, HF:71-83)
     const float* pix;
     int C_in, R, P, G;

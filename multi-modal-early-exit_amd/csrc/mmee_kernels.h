@@ -131,7 +131,8 @@ void launch_embed_visual(const EmbedArgs& a, hipStream_t s);
 void launch_pool_finish(const float* part, int chunks, int H, float count, float* pooled, int B, hipStream_t s);
 void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
                     const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split = nullptr,
-                    float split_scale = 1.0f, int* err_flag = nullptr);
+                    float split_scale = 1.0f, int* err_flag = nullptr, int pre_parts = 0, size_t pre_stride = 0, const float* pre_bias = nullptr,
+                    const void* pre_resid = nullptr, float pre_resid_inv = 0.f);
 void launch_embed_beit(const float* patch, const float* cls, const float* pos, int B, int Pv, int H, float* X, hipStream_t s);
 void launch_patch_mean(const float* X, int H, const int* x_phys, const int* doc_off, const int* n_docs_ptr, float* pooled,
                        int max_docs, hipStream_t s);

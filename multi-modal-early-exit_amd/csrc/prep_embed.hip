@@ -380,11 +380,20 @@ __global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restric
 
 // row LayerNorm over the packed rows of the active stage: dst[r] = LN(src[row_src ? row_src[r] : r]) (dst may be src or
 // null); dst_split, when given, receives the same row as split-f16 planes (the A operand of the next split GEMM)
-template <int NV>
+// pre (CLS-probe rows under MMEE_FLAG_XPROBE only): the row is first completed from the n_parts split-K partial planes of the GEMM in
+// front (src + p * part_stride, added in order p = 0, 1, ...), its bias and the residual row (split planes scaled by 1 / resid_inv).
+struct LnPre {
+    int n_parts;
+    size_t part_stride;
+    const float* bias;
+    const char* resid;
+    float resid_inv;
+};
+template <int NV, bool PRE>      // PRE is a separate instantiation: the layers' own LayerNorm launches carry none of its code
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                      char* __restrict__ dst_split, float split_scale, int* __restrict__ err_flag) {
+                                                      char* __restrict__ dst_split, float split_scale, int* __restrict__ err_flag, const LnPre pre) {
     const int n_rows = *n_rows_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float amax = 0.f;
@@ -395,6 +404,17 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
             x[i] = (c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = 4 * lane + 256 * i;
+                if (c < H) {
+                    for (int q = 1; q < pre.n_parts; ++q) x[i] += *reinterpret_cast<const f32x4*>(p + (size_t)q * pre.part_stride + c);
+                    if (pre.bias) x[i] += *reinterpret_cast<const f32x4*>(pre.bias + c);
+                    if (pre.resid) x[i] += load_split4(pre.resid + (size_t)r * H * 4, c, pre.resid_inv);
+                }
+            }
         }
         wave_layernorm<NV>(x, H, lane, g, b, eps);
         if (dst) wave_store_row<NV>(dst + (size_t)r * H, x, H, lane);
@@ -511,18 +531,20 @@ void launch_pool_finish(const float* part, int chunks, int H, float count, float
 }
 
 void launch_ln_rows(const float* src, float* dst, const int* row_src, const int* n_rows_ptr, int max_rows, int H,
-                    const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split_v, float split_scale, int* err_flag) {
+                    const float* g, const float* b, float eps, int num_cus, hipStream_t s, void* dst_split_v, float split_scale, int* err_flag,
+                    int pre_parts, size_t pre_stride, const float* pre_bias, const void* pre_resid, float pre_resid_inv) {
     char* dst_split = reinterpret_cast<char*>(dst_split_v);
+    const LnPre pre{pre_parts, pre_stride, pre_bias, reinterpret_cast<const char*>(pre_resid), pre_resid_inv};
     int grid = (max_rows + 3) / 4;
     const int cap = num_cus * 8;
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int nv = (H + 255) / 256;
     switch (nv) {
-        case 1: hipLaunchKernelGGL(ln_rows_kernel<1>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
-        case 2: hipLaunchKernelGGL(ln_rows_kernel<2>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
-        case 3: hipLaunchKernelGGL(ln_rows_kernel<3>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
-        default: hipLaunchKernelGGL(ln_rows_kernel<4>, dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag); break;
+        case 1: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<1, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<1, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
+        case 2: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<2, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
+        case 3: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<3, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<3, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
+        default: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<4, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
     }
 }
 
