@@ -12,7 +12,9 @@ tests/test_host.py.  It is host-side numpy on N confidences per exit (a sort and
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
+
+import warnings
 
 import numpy as np
 
@@ -95,7 +97,7 @@ def fit_temperatures(logits, labels, max_iter: int = 100, device=None, with_ece:
     return res
 
 
-def calibrate(validation_logits, validation_references, test_logits, device=None, metrics_on: str = "validation"):
+def calibrate(validation_logits, validation_references, test_logits, device=None, metrics_on: Optional[str] = None):
     """The loop of ``calibrate()`` (EE/eval.py:277-346) without its file cache: one temperature per exit fitted on the
     validation logits, the test logits divided by it, and ``calibration_metrics`` = {ece, accuracy, temperature,
     average_confidence} (lists, one entry per exit) — the dictionary ``Policy.accuracy_calibration_heuristic`` reads
@@ -103,7 +105,9 @@ def calibrate(validation_logits, validation_references, test_logits, device=None
 
     ``metrics_on`` says which logits the three metrics are taken from:
 
-    * ``"validation"`` (default, a DEVIATION from the reference): the scaled VALIDATION logits against the validation references —
+    * ``None`` (default): ``"reference"`` whenever the reference itself could run, i.e. when the test and validation sets have the same
+      number of samples — a drop-in caller gets the thresholds the reference derives; otherwise ``"validation"`` with a warning.
+    * ``"validation"`` (a documented DEVIATION from the reference): the scaled VALIDATION logits against the validation references —
       the set the temperatures were fitted on and the labels belong to.
     * ``"reference"``: exactly what EE/eval.py:321-337 computes — ``ece_logits(validation_references, calibrated_logits[i])``,
       ``softmax(calibrated_logits[i]).max(-1).mean()`` and ``mean(calibrated_logits[i].argmax(-1) == validation_references)`` with
@@ -111,8 +115,15 @@ def calibrate(validation_logits, validation_references, test_logits, device=None
       when both sets have the same number of samples (it raises otherwise, as numpy does in the reference) and only means
       something when they are the same samples; the thresholds the heuristic derives differ between the two modes.
     """
+    if metrics_on is None:
+        same = np.asarray(test_logits).shape[1] == np.asarray(validation_references).reshape(-1).shape[0]
+        metrics_on = "reference" if same else "validation"
+        if not same:
+            warnings.warn("calibrate(): the test and validation sets differ in length, so EE/eval.py:321-337 (scaled TEST logits scored "
+                          "against the VALIDATION references) cannot be evaluated; the calibration metrics are taken from the scaled "
+                          'validation logits instead (metrics_on="validation")', stacklevel=2)
     if metrics_on not in ("validation", "reference"):
-        raise ValueError('metrics_on must be "validation" or "reference"')
+        raise ValueError('metrics_on must be None, "validation" or "reference"')
     fit = fit_temperatures(validation_logits, validation_references, device=device, with_ece=metrics_on == "validation")
     T = fit["temperature"]
     cal = np.asarray(test_logits, dtype=np.float64) / T[:, None, None]

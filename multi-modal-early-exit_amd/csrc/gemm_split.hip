@@ -113,6 +113,7 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
                 const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
                 stg[r * 64 + ni * 32 + l31] = acc[mi][ni][e];
             }
+        asm volatile("" ::: "memory");      // float writes, f32x4 reads: keep the compiler from hoisting the reads (see split_store_tile16)
         const int rbase = m0 + wr * 64 + mi * 32 + (lane >> 4);
 #pragma unroll 4
         for (int j = 0; j < 8; ++j) {
@@ -188,8 +189,21 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
     float* stg = smem + wave * (RB * 64);
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wc * 64 + c4;
-    const float sc = (col < g.scale_cols) ? g.scale : 1.0f;
-    const float alpha = g.alpha;
+    const float sc = (col < g.scale_cols) ? g.scale : 1.0f;      // scale_cols is a multiple of 64: uniform over the wave
+    // Round 4: the epilogue is VALU-issue bound (one wave64 instruction per four cycles per SIMD, the matrix pipe idle), so everything that
+    // can be folded is: a power-of-two Q scale and the (power-of-two) plane scale of a split output go into alpha and the bias -- exact --
+    // so a bias element is ONE fma; the activation forms take the unscaled value and produce the scaled one (gelu_scaled2); a Q scale that is
+    // not a power of two (no supported model) and the BEiT per-column factor sit behind wave-uniform branches
+    const float s_out = OUT_SPLIT ? g.out_scale : 1.0f;
+    constexpr bool ACT = EPI == EPI_GELU || EPI == EPI_TANH;
+    const bool sc_p2 = (__float_as_uint(sc) & 0x007fffffu) == 0u;
+    const float fold = ACT ? 1.0f : s_out * (sc_p2 ? sc : 1.0f);
+    const float post = ACT ? sc : (sc_p2 ? 1.0f : sc);
+    const bool need_post = __builtin_amdgcn_readfirstlane((int)__float_as_uint(post)) != 0x3f800000;
+    const bool need_lam = g.col_scale != nullptr;
+    const float alpha_e = g.alpha * fold;
+    const f32x4 be = bv * fold;
+    const float gelu_c0 = __builtin_log2f(s_out) - 1.0f, gelu_hs = 0.5f * s_out;
     float amax = 0.f;
 #pragma unroll
     for (int half = 0; half < 64 / RB; ++half) {
@@ -202,22 +216,28 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
                     const int r = 16 * m2 + 4 * gq + e;                      // (r >> 2) & 1 == gq & 1
                     stg[r * 64 + ((ni * 16 + l15) ^ (16 * (gq & 1)))] = acc[(RB / 16) * half + m2][ni][e];
                 }
+        // The staging block is written as floats and read back as f32x4: without this compiler barrier hipcc may (and, after the round-4
+        // edits, did) hoist the first read above half of the writes -- type-based alias analysis sees no conflict.  The hardware needs
+        // nothing: a wave's LDS operations execute in order.
+        asm volatile("" ::: "memory");
         const int rbase = m0 + wr * 64 + half * RB + (lane >> 4);
 #pragma unroll 4
         for (int j = 0; j < RB / 4; ++j) {
             const int rl = (lane >> 4) + 4 * j;
             const int row = rbase + 4 * j;
             f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 64 + (c4 ^ (16 * ((rl >> 2) & 1))));
-            if (row < M) {
+            // (rows past M compute on whatever the clamped A rows gave and are not stored; the quad permute below needs every lane)
 #pragma unroll
-                for (int t = 0; t < 4; t += 2) {
-                    f32x2 x = __builtin_elementwise_fma(f32x2{v[t], v[t + 1]}, (f32x2)(alpha), f32x2{bv[t], bv[t + 1]}) * (f32x2)(sc);
-                    if (EPI == EPI_GELU) x = gelu_erf2(x);
-                    if (EPI == EPI_TANH) { x[0] = tanhf(x[0]); x[1] = tanhf(x[1]); }
-                    x = x * f32x2{lam[t], lam[t + 1]};
-                    v[t] = x[0];
-                    v[t + 1] = x[1];
-                }
+            for (int t = 0; t < 4; t += 2) {
+                f32x2 x = __builtin_elementwise_fma(f32x2{v[t], v[t + 1]}, (f32x2)(alpha_e), f32x2{be[t], be[t + 1]});
+                if (need_post) x = x * (f32x2)(post);
+                if (EPI == EPI_GELU) x = gelu_scaled2(x, gelu_c0, gelu_hs);
+                if (EPI == EPI_TANH) { x[0] = tanhf(x[0]) * s_out; x[1] = tanhf(x[1]) * s_out; }
+                if (need_lam) x = x * f32x2{lam[t], lam[t + 1]};
+                v[t] = x[0];
+                v[t + 1] = x[1];
+            }
+            if (row < M) {
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
                     if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
@@ -226,11 +246,19 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
                 if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + c_shift + (size_t)row * g.ldc + col) = v;
             }
             if (OUT_SPLIT) {
-                f16x4 hi, lo;
-                split_f16x4(row < M ? v : f32x4{0.f, 0.f, 0.f, 0.f}, g.out_scale, hi, lo, amax);
-                const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
+                // The four lanes of a quad hold columns 4q .. 4q+3 of one 16-column group, whose 64 output bytes are
+                // [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]: a quad permute hands lane q the 16-byte piece number q, so the row leaves as
+                // one fully coalesced 16-byte-per-lane store: consecutive lanes on consecutive bytes, 4 rows x 256 B per instruction -- the
+                // only shape the store path takes at speed (tools/store_rate.hip).  Every lane takes part in the permute.
+                int2 h2, l2;
+                {
+                    unsigned h01, h23, l01, l23;
+                    split_pair(v[0], v[1], h01, l01, amax);
+                    split_pair(v[2], v[3], h23, l23, amax);
+                    h2.x = (int)h01; h2.y = (int)h23; l2.x = (int)l01; l2.y = (int)l23;
+                }
                 const bool take_lo = (lane & 2) != 0;
-                int4 piece;
+                int4 piece;       // lane q: q = 0 -> hi of lanes 0,1; 1 -> hi of lanes 2,3; 2 -> lo of lanes 0,1; 3 -> lo of lanes 2,3
                 {
                     const int a0 = __builtin_amdgcn_mov_dpp(h2.x, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp(h2.y, 0x88, 0xf, 0xf, true);
                     const int b0 = __builtin_amdgcn_mov_dpp(l2.x, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp(l2.y, 0x88, 0xf, 0xf, true);
@@ -245,6 +273,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
                     *reinterpret_cast<int4*>(reinterpret_cast<char*>(g.C) + (size_t)row * g.ldc * 4 + (size_t)(col >> 4) * 64 + (lane & 3) * 16) = piece;
             }
         }
+        asm volatile("" ::: "memory");      // ... and the next slice's writes stay behind this slice's reads
     }
     if (OUT_SPLIT) split_flag_overflow(amax, g.err_flag);
 }
@@ -534,13 +563,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
 
 template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0>
 static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = Cfg::LOOP_BYTES + 16;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>), (int)lds);
     const int tiles = ((max_m + Cfg::BM - 1) / Cfg::BM) * (a.N / Cfg::BN) * (TAG == 1 && a.k_splits > 1 ? a.k_splits : 1);
     int grid = Cfg::WGS * num_cus;
     if (grid > tiles) grid = tiles;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <stdlib.h>
+#include <mutex>
 
 namespace mmee {
 
@@ -17,6 +18,32 @@ inline int diag_env_int(const char* name, int dflt) {
     (void)name;
     return dflt;
 #endif
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): remembered per device, so a second GPU in the same process
+// gets its opt-in too (the launchers used to keep one process-wide flag), and a failure is returned instead of discarded.
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
+    constexpr int kMaxDev = 64, kMaxFn = 96;
+    struct Entry { const void* fn; int bytes[kMaxDev]; };
+    static Entry table[kMaxFn];
+    static int n_fn = 0;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry* e = nullptr;
+    for (int i = 0; i < n_fn; ++i)
+        if (table[i].fn == kernel) { e = &table[i]; break; }
+    if (!e) {
+        if (n_fn == kMaxFn) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e = &table[n_fn++];
+        e->fn = kernel;
+        for (int d = 0; d < kMaxDev; ++d) e->bytes[d] = 0;
+    }
+    if (e->bytes[dev] >= bytes) return hipSuccess;
+    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == hipSuccess) e->bytes[dev] = bytes;
+    return rc;
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -151,6 +178,39 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {      // x * 0.5 * (1 + erf
     return (x * (f32x2)(0.5f)) * ((f32x2)(1.0f) + e);
 }
 
+// Round 4: s * GELU(x) with fewer instructions (a wave64 VALU instruction holds its SIMD for four cycles, packed or not, and the matrix pipe
+// idles during the GEMM epilogue, so the epilogue costs its instruction count): with erf(z) = sign(z) (1 - 2^-q(|z|)) and t = 2^-q / 2,
+//     GELU(x) = x Phi(x) = x (1 - t) for x >= 0, x t for x < 0   =   fma(|x|, 1/2 - t, x / 2),
+// so there is no copysign and no 1 - e; the x / sqrt 2 of the argument is folded into the coefficients (polynomial in |x| directly, clamp at
+// 4 sqrt 2) and a power-of-two output scale s into the exponent (s t = 2^(log2 s - 1 - q)): 16 instructions per PAIR against 22.  Max abs
+// error against float64 3.7e-7 (the form above: 5.0e-7).  c0 = log2(s) - 1, hs = s / 2.
+constexpr float kGeluD1 = -1.151104450e+00f, kGeluD2 = -4.592170119e-01f, kGeluD3 = -5.246298015e-02f, kGeluD4 = 7.006162778e-03f,
+                kGeluD5 = -8.593643724e-05f, kGeluD6 = -2.103079314e-04f, kGeluD7 = 4.510273720e-05f, kGeluD8 = -3.368171292e-06f;
+constexpr float kGeluClamp = 5.656854249f;       // 4 sqrt 2: the fit of q covers |x| / sqrt 2 in [0, 4]; erfc(4) = 1.5e-8
+__device__ __forceinline__ f32x2 gelu_scaled2(const f32x2 x, const float c0, const float hs) {
+    f32x2 a;
+    a[0] = fminf(fabsf(x[0]), kGeluClamp);
+    a[1] = fminf(fabsf(x[1]), kGeluClamp);
+    f32x2 p = (f32x2)(kGeluD8);
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD7));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD6));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD5));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD4));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD3));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD2));
+    p = __builtin_elementwise_fma(p, a, (f32x2)(kGeluD1));
+    const f32x2 u = __builtin_elementwise_fma(p, a, (f32x2)(c0));      // log2(s t) = log2 s - 1 - q
+    f32x2 t;
+    t[0] = __builtin_amdgcn_exp2f(u[0]);
+    t[1] = __builtin_amdgcn_exp2f(u[1]);
+    const f32x2 h = (f32x2)(hs) - t;
+    const f32x2 xh = x * (f32x2)(hs);
+    f32x2 r;
+    r[0] = fmaf(fabsf(x[0]), h[0], xh[0]);
+    r[1] = fmaf(fabsf(x[1]), h[1], xh[1]);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Split-f16 operand rows (precision mode MMEE_PREC_F32_SPLIT, gemm_split.hip).  A row of K f32 values x[k] is kept in the same
 // 4*K bytes as K/16 groups of 64 bytes: group j = [hi[16j .. 16j+15] (32 B) | lo[16j .. 16j+15] (32 B)] with
@@ -177,6 +237,21 @@ __device__ __forceinline__ void split_f16x4(const f32x4& v, float scale, f16x4& 
         hi[t] = h[0]; hi[t + 1] = h[1];
         lo[t] = l[0]; lo[t + 1] = l[1];
     }
+}
+// Round 4, the GEMM epilogues' form: (x0, x1) ALREADY scaled -> packed hi pair and packed lo pair in 4 instructions (v_max3_f32,
+// v_cvt_pk_f16_f32, and lo = f16(x - float(hi)) by one v_fma_mixlo / mixhi_f16 each: fma(x, 1.0, -hi) in f32 is exact and rounds once) against
+// 11 for the form above.  No clamp: |x| > 65504 becomes inf in the hi plane and the forward is REFUSED through kErrSplitOverflow exactly as
+// before (amax sees every element); values in (60000, 65504] are now converted correctly instead of clamped.
+__device__ __forceinline__ void split_pair(const float x0, const float x1, unsigned& hb, unsigned& lb, float& amax) {
+    amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
+    const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
+    hb = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"       // the GEMM epilogue reads `lb` with v_mov_b32_dpp next: a DPP source needs two wait states after the VALU write, and the
+                        // hazard recognizer does not see a VALU write inside an asm statement (rows 2-3 of every 16 came out stale without it)
+        : "=&v"(lb)
+        : "v"(x0), "v"(x1), "v"(hb));
 }
 // store 4 consecutive columns [col, col+4) (col % 4 == 0) of a split row
 __device__ __forceinline__ void split_flag_overflow(float amax, int* err_flag) {

@@ -25,6 +25,20 @@ def oracle():
     return importlib.import_module("oracle.ee_oracle")
 
 
+def report_measured(test, what, value):
+    """Record a MEASURED parity error (not a tolerance): printed, and appended to gpurun_out/parity_measured.txt so that a GPU run
+    leaves the numbers behind (copied to profiles/ per round)."""
+    line = f"{test}: {what} = {value:.3e}"
+    print(line)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 

@@ -421,7 +421,7 @@ def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
     val[:, np.arange(N), labels] += 1.2 * sharp[:, 0]
     val *= np.array([3.0, 0.5, 2.0, 1.0, 4.0])[:, None, None]                # each exit mis-calibrated by a different factor
     test = val[:, ::-1].copy()
-    cal, metrics = pkg.calibration.calibrate(val, labels, test)
+    cal, metrics = pkg.calibration.calibrate(val, labels, test, metrics_on="validation")
     assert set(metrics) == {"ece", "accuracy", "temperature", "average_confidence"} and all(len(v) == E1 for v in metrics.values())
     T = np.array(metrics["temperature"])
     np.testing.assert_allclose(cal, test / T[:, None, None], rtol=1e-12)
@@ -443,6 +443,12 @@ def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
     assert m_r["accuracy"] != metrics["accuracy"]            # `test` is the validation set reversed: its argmax no longer matches the labels
     with pytest.raises(ValueError):
         pkg.calibration.calibrate(val, labels, test[:, :-1], metrics_on="reference")
+    # the default follows the reference whenever the reference could run (equal lengths), and says so when it cannot
+    _, m_d = pkg.calibration.calibrate(val, labels, test)
+    assert m_d == m_r
+    with pytest.warns(UserWarning):
+        _, m_w = pkg.calibration.calibrate(val, labels, test[:, :-1])
+    assert m_w == metrics
     cfgp = {"exit_threshold": 0.5, "device": "cpu", "epsilon": 0.05, "calibration_metrics": metrics}
     ex, pred, dist = pkg.Policy(cal, cfgp).accuracy_calibration_heuristic()
     thr = oracle.heuristic_thresholds(metrics["accuracy"], metrics["ece"], 0.05)
