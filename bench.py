@@ -405,7 +405,7 @@ def main(argv=None):
         sl = (lambda t: t if (t is None or n is None or n == B) else t[:n])
         xp = a.xprobe if xprobe is None else xprobe
         return eng.forward(sl(d_ids), sl(d_am), sl(d_bb), sl(d_px), thresholds=thr, dense_rows=a.dense_rows, temperatures=temps,
-                           whole_layers=a.whole_layers, probe_always=a.probe_always, **({"xprobe": True} if xp else {}))
+                           whole_layers=a.whole_layers, probe_always=a.probe_always, xprobe=bool(xp))
 
     # ---- the job: weak scaling = K full batches per rank; strong scaling = --total-docs dealt round-robin ----------
     strong = a.total_docs > 0
@@ -522,6 +522,10 @@ def main(argv=None):
         "exit_distribution": {str(int(layer_of_exit[e])): float((exits == e).mean()) for e in range(len(layer_of_exit))},
         "stage_docs_last_step_rank0": counts["docs"], "executed_tflop_per_step_rank0": fl["total"] / 1e12,
         "executed_tflops_rank0": fl["total"] / (dt / steps) / 1e12,
+        # the WHOLE step against the matrix-pipe ceiling of its precision (split: f16 dense peak / 3 terms; fp32: the f32 MFMA peak): every
+        # kernel of the step is in the numerator's time, only executed GEMM / attention / probe flops in its work
+        "step_frac_of_ceiling": (fl["total"] / (dt / steps) / 1e12) /
+                                (PEAK_F32_MFMA_TFLOPS if eng.precision in ("fp32", "f32") else PEAK_F16_MFMA_TFLOPS / SPLIT_TERMS),
     }
     if per_rank is not None:
         line["per_rank"] = {"compute_ms": [round(float(x), 3) for x in per_rank[:, 0]], "docs": [int(x) for x in per_rank[:, 1]],
@@ -666,7 +670,7 @@ def main(argv=None):
         for batch in feeder:
             o = eng.forward(batch["input_ids"], batch["attention_mask"], batch["bbox"], batch["pixel_values"], thresholds=thr,
                             dense_rows=a.dense_rows, temperatures=temps, whole_layers=a.whole_layers, probe_always=a.probe_always,
-                            **({"xprobe": True} if a.xprobe else {}))
+                            xprobe=bool(a.xprobe))
             srows.append(pkg.dist.pack_results(o.logits, o.exit_layer, o.confidence))
         srows = torch.cat(srows, dim=0)
         torch.cuda.synchronize()
@@ -677,6 +681,11 @@ def main(argv=None):
         line["feed_inclusive"] = {"docs": len(stream), "distinct_documents": True, "seconds": sdt,
                                   "h2d_bytes_per_doc": feeder.bytes_h2d / max(1, len(stream)),
                                   "mean_exit_layer": float(layer_of_exit[sex].mean()),
+                                  "exit_distribution": {str(int(layer_of_exit[e])): float((sex == e).mean()) for e in range(len(layer_of_exit))},
+                                  "comparable_with_value": False,
+                                  "why_not": "DIFFERENT documents under the thresholds calibrated on the resident batch: they leave earlier or "
+                                             "later than the resident ones (compare mean_exit_layer / exit_distribution), so the two rates "
+                                             "measure different amounts of work; `value` re-runs the same resident batch every step",
                                   "what": "RawDocumentStream (1000x762 uint8 pages, ragged ids/boxes) -> DeviceFeeder (pinned double "
                                           "buffer, one async H2D copy per batch, resize/normalise/pad on a side stream) -> ee_forward; "
                                           "host packing, PCIe and preprocessing are inside the clock, page synthesis is not"}

@@ -48,7 +48,13 @@ class EarlyExitEngine:
     """One handle on one GPU.  Not thread-safe (same as the reference's one-model-per-process use)."""
 
     def __init__(self, cfg: ModelConfig, max_docs: int = 64, max_text_len: int = 512, precision: str = "auto",
-                 device=None):
+                 device=None, xprobe: Optional[bool] = None):
+        """``xprobe``: what ``forward(xprobe=None)`` runs at probe-first exit layers.  ``None`` (default): the X-space CLS probe
+        (MMEE_FLAG_XPROBE, csrc/xprobe.hip) wherever the library has it -- split precision, LayoutLMv3-base / -large shapes; the C side
+        falls back to the K | V probe elsewhere.  It is the faster valid schedule and the one ``bench.py`` measures: exit indices equal,
+        logits within the 1e-4 bar, but an exit's row is a re-association of the whole-layer arithmetic, NOT bit-identical to the dump-all
+        row.  ``False`` pins the K | V probe, whose rows are bit-identical to whole layers (the parity suite's bit-identity tests ask
+        for that)."""
         self.lib = capi.load()
         self.device = _require_torch_cuda(device)
         self.cfg = cfg
@@ -84,6 +90,7 @@ class EarlyExitEngine:
             precision = "split" if (cfg.hidden_size % 256 == 0 and cfg.intermediate_size % 256 == 0) else "fp32"
         c.precision = {"fp32": 0, "f32": 0, "bf16": 1, "split": 2, "f32_split": 2}[precision]
         self.beit = cfg.arch == "beit"
+        self.xprobe_default = (precision in ("split", "f32_split") and not self.beit) if xprobe is None else bool(xprobe)
         c.arch = 1 if self.beit else 0
         c.use_abs_pos = int(cfg.use_absolute_position_embeddings)
         c.layer_scale = int(cfg.layer_scale_init_value > 0)
@@ -179,7 +186,7 @@ class EarlyExitEngine:
                 position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
-                validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: bool = False) -> EngineOutput:
+                validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -227,6 +234,8 @@ class EarlyExitEngine:
         head_crit = torch.full((E, B), nan, dtype=torch.float32, device=dev) if want_head else None
         hidden = torch.full((self.cfg.num_hidden_layers + 1, B, self.cfg.hidden_size), nan, dtype=torch.float32,
                             device=dev) if want_hidden_cls else None
+        if xprobe is None:
+            xprobe = self.xprobe_default
         flags = ((capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0) |
                  (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0) |
                  (capi.FLAG_XPROBE if xprobe else 0))

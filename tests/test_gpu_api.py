@@ -111,7 +111,7 @@ def test_policy_kernel_full_size_properties(pkg, oracle):
 def test_input_validation_flags(pkg):
     g = load_golden("tiny_ramp")
     cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
-    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48, xprobe=False)
     with pytest.raises(pkg.capi.MMEEError):
         eng.forward(g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"])   # weights not loaded
     eng.load_weights(pkg.synth.make_weights(cfg, seed=7))
@@ -141,7 +141,7 @@ def test_error_of_an_earlier_forward_survives_later_forwards(pkg):
     import torch
     g = load_golden("tiny_ramp")
     cfg = pkg.ModelConfig.tiny(EE_config=TINY_CASES["tiny_ramp"])
-    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=48, xprobe=False)
     eng.load_weights(pkg.synth.make_weights(cfg, seed=7))
     good = (g["in_input_ids"], g["in_attention_mask"], g["in_bbox"], g["in_pixel_values"])
     bad_box = g["in_bbox"].copy()
@@ -183,7 +183,7 @@ def test_error_of_an_earlier_forward_survives_later_forwards(pkg):
     W = pkg.synth.make_weights(cfg, seed=7)
     W.pop("classifier.dense.weight")
     with pytest.raises(KeyError):
-        pkg.EarlyExitEngine(cfg, max_docs=2, max_text_len=48).load_weights(W)
+        pkg.EarlyExitEngine(cfg, max_docs=2, max_text_len=48, xprobe=False).load_weights(W)
     eng.close()
 
 
@@ -257,7 +257,7 @@ def test_large_shape_gate_temperature_matches_oracle(pkg, oracle):
     W = pkg.synth.make_weights(cfg, seed=21)
     docs = pkg.synth.make_documents(cfg, 5, seed=22, text_len=40, min_words=2)
     ref = oracle.forward_all(cfg, W, docs, ee["exits"], strategy="gate", return_hidden_cls=True)
-    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40, xprobe=False)
     eng.load_weights(W)
     out = eng.forward(docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"], dump_all=True,
                       want_all=True, want_head=True, want_hidden_cls=True, validate=True)

@@ -58,7 +58,7 @@ def test_config3_full_size_against_cpu_restatement(pkg, oracle):
     tor = otorch.TorchOracle(cfg, W)
     refs = [tor.forward_all({k: v[i:i + 1] for k, v in docs.items()}, ee["exits"], strategy="gate") for i in range(N)]
     store = np.concatenate([r["logits_store"] for r in refs], axis=1)                  # (24, N, 16)
-    eng = pkg.EarlyExitEngine(cfg, max_docs=N, max_text_len=512)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=N, max_text_len=512, xprobe=False)
     assert eng.precision == "split"
     eng.load_weights(W)
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
@@ -100,7 +100,7 @@ def test_config3_full_size_properties(pkg, oracle):
     ee, cfg, W, temps = _config3(pkg)
     B = 64
     docs = pkg.synth.make_documents(cfg, B, seed=78, text_len=512)
-    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=512)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=512, xprobe=False)
     eng.load_weights(W)
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
     raw = eng.forward(*args, dump_all=True, want_all=True, validate=True)
@@ -176,7 +176,7 @@ def test_split_precision_with_checkpoint_like_statistics(pkg, oracle):
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
     errs = {}
     for prec in ("fp32", "split"):
-        eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40, precision=prec)
+        eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=40, precision=prec, xprobe=False)
         eng.load_weights(W)
         out = eng.forward(*args, dump_all=True, want_all=True, want_hidden_cls=True, validate=True)
         errs[prec] = (float(np.abs(_np(out.all_logits) - ref["logits_store"]).max()),
@@ -197,7 +197,7 @@ def test_split_precision_overflow_fails_loudly(pkg, oracle):
     W = _checkpoint_like(pkg, cfg, seed=41, gamma_outliers=(5000.0,), weight_tail=0.0, pos_gain=1.0)
     docs = pkg.synth.make_documents(cfg, 4, seed=42, text_len=40, min_words=2)
     args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
-    eng = pkg.EarlyExitEngine(cfg, max_docs=4, max_text_len=40, precision="split")
+    eng = pkg.EarlyExitEngine(cfg, max_docs=4, max_text_len=40, precision="split", xprobe=False)
     eng.load_weights(W)
     with pytest.raises(pkg.capi.MMEEError, match="overflow"):
         eng.forward(*args, dump_all=True, validate=True)
@@ -211,7 +211,7 @@ def test_split_precision_overflow_fails_loudly(pkg, oracle):
         eng.forward(*args, dump_all=True)                     # ... and so does the next call
     eng.close()
     ref = oracle.forward_all(cfg, W, docs, ee["exits"])
-    e32 = pkg.EarlyExitEngine(cfg, max_docs=4, max_text_len=40, precision="fp32")
+    e32 = pkg.EarlyExitEngine(cfg, max_docs=4, max_text_len=40, precision="fp32", xprobe=False)
     e32.load_weights(W)
     out = e32.forward(*args, dump_all=True, want_all=True, validate=True)
     scale = float(np.abs(ref["logits_store"]).max())

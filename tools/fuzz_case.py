@@ -47,7 +47,7 @@ if len(sys.argv) > 2:      # poison: freed device memory keeps this pattern, so 
 W = pkg.synth.make_weights(cfg, seed=ws, head_gain=6.0)
 docs = pkg.synth.make_documents(cfg, B, seed=ds, text_len=T, min_words=1)
 args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
-eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision="split")
+eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision="split", xprobe=False)      # bit-identity between schedules is asserted; the X-space probe is asked for explicitly
 eng.load_weights(W)
 torch.cuda.synchronize()
 print("forward dump_all", flush=True)

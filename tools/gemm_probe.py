@@ -55,10 +55,57 @@ def run(M, N, K, epi=0, wgs=2, iters=10, check=False, fold=0):
     return tf
 
 
-if __name__ == "__main__" and os.path.basename(sys.argv[0]) == "gemm_probe.py":
-    run(4096, 768, 768, check=True)
-    M = 512 * 462
-    for wgs in (1, 2):
-        run(M, 3072, 768, epi=1, wgs=wgs)
-        run(M, 768, 3072, epi=2, wgs=wgs)
-        run(M, 2304, 768, epi=0, wgs=wgs)
+MB = 512 * 462
+
+
+def cmd_variants():
+    """register-staged vs LDS-DMA kernel (epi | 256), correctness + rate at the layer shapes"""
+    for flag in (256, 0):
+        print("LDS-DMA" if flag else "register-staged")
+        run(4096 + 77, 768, 768, check=True, epi=2 | flag)
+        run(300, 768, 768, check=True, epi=1 | flag)
+        run(4096 + 77, 768, 768, check=True, epi=0 | flag, fold=37)
+        for N, K, e in ((3072, 768, 1), (768, 3072, 2), (2304, 768, 0)):
+            run(MB, N, K, epi=e | 64 | flag, wgs=0, iters=5)
+
+
+def cmd_diag():
+    """timing variants of the LDS-DMA kernel (WRONG results): what the k-loop barrier, the DMA issue and the wait cost"""
+    for flag, name in ((256, "DMA"), (256 | 32, "DMA, no in-loop DMA issue"), (256 | 512, "DMA, no k-loop barrier"), (256 | 1024, "DMA, no vmcnt wait"),
+                       (256 | 1024 | 512, "DMA, no vmcnt wait, no barrier")):
+        print(name)
+        run(MB, 768, 3072, epi=0 | 64 | flag, wgs=0, iters=5)
+        run(MB, 2304, 768, epi=0 | 64 | flag, wgs=0, iters=5)
+        run(MB, 768, 3072, epi=0 | flag, wgs=0, iters=5)
+
+
+def cmd_stagger():
+    """does starting the second workgroup of each CU out of phase help? (epi bits 12..: stagger)"""
+    for st in (0, 6, 12, 18):
+        print("stagger", st)
+        for N, K, e in ((3072, 768, 1), (768, 3072, 2), (2304, 768, 0)):
+            run(MB, N, K, epi=e | 256 | (st << 12), wgs=0, iters=5)
+
+
+def cmd_queue():
+    """static grid stride (epi | 16) vs XCD-local work queues"""
+    run(4096 + 77, 768, 768, check=True, epi=2)
+    run(300, 768, 768, check=True, epi=1)
+    for mode, name in ((16, "static grid stride"), (0, "XCD-local queues")):
+        print(name)
+        for N, K, e in ((3072, 768, 1), (768, 3072, 2), (2304, 768, 0)):
+            run(MB, N, K, epi=e | mode | 64, wgs=0, iters=5)
+
+
+
+
+if __name__ == "__main__":
+    # python tools/gemm_probe.py [variants|diag|stagger|queue]  (rounds 1-2 had one ten-line script per experiment)
+    if len(sys.argv) > 1:
+        {"variants": cmd_variants, "diag": cmd_diag, "stagger": cmd_stagger, "queue": cmd_queue}[sys.argv[1]]()
+    else:
+        run(4096, 768, 768, check=True)
+        for wgs in (1, 2):
+            run(MB, 3072, 768, epi=1, wgs=wgs)
+            run(MB, 768, 3072, epi=2, wgs=wgs)
+            run(MB, 2304, 768, epi=0, wgs=wgs)
