@@ -70,6 +70,10 @@ enum {
                                   exit layer from the stage populations of the handle's most recent finished forward (a probe
                                   pays when enough rows leave; the last layer is always probed).  All three give identical
                                   results bit for bit: the flags only pin the schedule, for A/B runs and tests          */
+    MMEE_FLAG_ONE_TERM = 32,   /* REPORTED low-precision mode, never a parity path (SURVEY 8d config 2 "bf16 throughput mode reports its measured
+                                  deviation separately"): the layer GEMMs and the attention of an MMEE_PREC_F32_SPLIT LayoutLMv3 handle run ONE f16
+                                  MFMA term per MAC (hi planes only, f32 accumulate) instead of three; CLS probes and exit heads keep three.  Logits
+                                  leave the 1e-4 bar and exit indices may flip: bench.py reports rate, max |dlogit| and flip rate as `lowprec` */
     MMEE_FLAG_XPROBE = 16      /* probe-first layers take the CLS context in X space (csrc/xprobe.hip): score_j = (W_k^T q) . x_j + q . b_k,
                                   ctx = W_v (sum_j p_j x_j) + b_v.  No Q | K | V projection exists when the decision is taken: the layer's
                                   Q | K | V GEMM then runs for the documents that STAY only, and not at all in the last layer.  A

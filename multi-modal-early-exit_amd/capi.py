@@ -17,6 +17,7 @@ FLAG_NO_EXIT = 2
 FLAG_WHOLE_LAYERS = 4
 FLAG_PROBE_ALWAYS = 8
 FLAG_XPROBE = 16
+FLAG_ONE_TERM = 32
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _LIB_NAME = "libmmee_hip.so"

@@ -175,7 +175,8 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // issue no DMA: correct, but 13.8 ms -- a workgroup's six waves land 2, 2, 1, 1 on the four SIMDs and a second workgroup of 168-VGPR waves
 // does not fit beside it, so a CU runs six waves instead of twelve).
 constexpr int kXP = 2;
-template <int MODE, bool BIAS, int XP>
+// TERMS = 1 (MMEE_FLAG_ONE_TERM, a reported low-precision mode, never a parity path): both products on the hi planes only.
+template <int MODE, bool BIAS, int XP, int TERMS = 3>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -393,11 +394,12 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                     const float x0 = s[8 * ks + 2 * j], x1 = s[8 * ks + 2 * j + 1];
                     const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);
                     const unsigned hb = __builtin_bit_cast(unsigned, h);
-                    unsigned lb;
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-                        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                        : "=&v"(lb)
-                        : "v"(x0), "v"(x1), "v"(hb));
+                    unsigned lb = 0u;
+                    if (TERMS == 3)
+                        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+                            "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(lb)
+                            : "v"(x0), "v"(x1), "v"(hb));
                     hw[j] = hb;
                     lw[j] = lb;
                 }
@@ -419,12 +421,16 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { vh[j] = a0[j]; vh[4 + j] = a1[j]; vl[j] = b0[j]; vl[4 + j] = b1[j]; }
                     if (dh == 0) {
-                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
-                        st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
+                        if (TERMS == 3) {
+                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o0, 0, 0, 0);
+                            st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o0, 0, 0, 0);
+                        }
                         st.o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o0, 0, 0, 0);
                     } else {
-                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
-                        st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
+                        if (TERMS == 3) {
+                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph8, st.o1, 0, 0, 0);
+                            st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl8, st.o1, 0, 0, 0);
+                        }
                         st.o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph8, st.o1, 0, 0, 0);
                     }
                 }
@@ -528,12 +534,12 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                     khn = lds_load<f16x8>(kb ^ (32u * (stp + 1)));
                     kln = lds_load<f16x8>(kb ^ (32u * (stp + 1) + 128u));
                 }
-                if (!(MODE == 2 && (dbg & 128))) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
+                if (!(MODE == 2 && (dbg & 128)) && TERMS == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
                 else asm volatile("" :: "v"(kl), "v"(kh));
                 if (VAR == V_HOT) issue_full(kt + 2, sb2, stp);
                 if (VAR == V_TAIL) issue_tail(kt + 2, sb2, stp);
                 if (!(MODE == 2 && (dbg & 128))) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
+                    if (TERMS == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
                 }
                 kh = khn;
@@ -613,28 +619,24 @@ bool attention_idx_supports(const AttnArgs& a) {
     return a.ctx_split && (a.pair_idx == nullptr || (a.bins1 >= 1 && a.bins1 <= BINS_MAX && a.bins2 >= 1 && a.bins2 <= BINS_MAX));
 }
 
-template <bool BIAS, int XP>
+template <bool BIAS, int XP, int TERMS = 3>
 static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS, XP, TERMS>), LDS_BYTES);
 #ifdef MMEE_DIAG
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS, XP>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS, XP, TERMS>), LDS_BYTES);
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS, XP, TERMS>), LDS_BYTES);
 #endif
-        attr_set = true;
-    }
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
     int grid = WGS * num_cus;
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
 #ifdef MMEE_DIAG      // stamped build and timing variants (wrong results): diagnostic library only
-    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
-    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
+    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
 #endif
     (void)stamps; (void)dbg;
-    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS, XP>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
 }
 
 // a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
@@ -663,6 +665,7 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         }
     }
 #endif
+    if (a.terms == 1 && a.pair_idx && !stamps && !dbg) { launch_idx<true, kXP, 1>(a, max_docs, num_cus, nullptr, 0, s); return; }      // MMEE_FLAG_ONE_TERM
     if (a.pair_idx) launch_idx<true, kXP>(a, max_docs, num_cus, stamps, dbg, s);
     else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);
 }

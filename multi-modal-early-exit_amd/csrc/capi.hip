@@ -895,7 +895,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
 
     const bool sp = h->split;
     // split mode, LayoutLMv3: the embedding kernels wrote the rows as split planes (Xs); later layers get theirs from the LayerNorm kernel
-    auto run_gemm = [&](const GemmArgs& g, int epi) {
+    // MMEE_FLAG_ONE_TERM: the layer GEMMs and the attention of a split-precision LayoutLMv3 handle on ONE f16 MFMA term (hi planes only): the
+    // "bf16 throughput mode" of SURVEY 8d as a REPORTED deviation (bench.py `lowprec`), never a parity path; probes and heads keep three terms
+    const bool one_term = (flags & MMEE_FLAG_ONE_TERM) && sp;
+    auto run_gemm = [&](const GemmArgs& g_in, int epi) {
+        GemmArgs g = g_in;
+        g.terms = one_term ? 1 : 3;
         if (sp) launch_gemm_split(g, epi, max_rows, cus, s);
         else launch_gemm_f32(g, epi, AMODE_ROWS, max_rows, cus, s);
     };
@@ -903,6 +908,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     // ---- exit stages ---------------------------------------------------------------------------------------------
     int cur = 0, meta_cur = 0, exit_index = 0;
     auto fill_idx = [&](AttnArgs& at) {
+        at.terms = one_term ? 1 : 3;
         at.pair_idx = (use_idx && !beit) ? h->pair_idx : nullptr;
         at.idx_doc_stride = h->idx_stride; at.idx_nb = h->idx_nb; at.doc_orig = S_doc_orig(cur);
         at.w1 = h->rel1; at.wx = h->relx; at.wy = h->rely; at.bins1 = c.rel_pos_bins; at.bins2 = c.rel_2d_pos_bins;

@@ -280,7 +280,8 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
 
 // TAG only names the instantiation (1 = the CLS-probe launches of capi.hip, so that a profiler keeps them apart from the
 // layer's own GEMMs); the code is the same, and so is every result bit.
-template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0>
+// TERMS = 1 (MMEE_FLAG_ONE_TERM): only hi x hi -- plain f16 operands, f32 accumulate; the lo planes are fetched with their rows but never read.
+template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0, int TERMS = 3>
 __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmArgs g) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, ROWB = Cfg::ROWB, NST = Cfg::NST, WN = Cfg::WN, PA = Cfg::PA, PW = Cfg::PW;
     constexpr int STAGE_BYTES = Cfg::STAGE_BYTES, A_BYTES = Cfg::A_BYTES;
@@ -481,10 +482,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 for (int j = 0; j < 4; ++j) {
                     const f16x8 wh = *reinterpret_cast<const f16x8*>(sb + w_row16 + c16_hi + j * 16 * ROWB);
                     const f16x8 wl = *reinterpret_cast<const f16x8*>(sb + w_row16 + c16_lo + j * 16 * ROWB);
+                    if (TERMS == 3) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc16[i][j], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh, acc16[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc16[i][j], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl, acc16[i][j], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh, acc16[i][j], 0, 0, 0);
                 }
@@ -561,15 +564,15 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
     }
 }
 
-template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0>
+template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0, int TERMS = 3>
 static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStream_t s) {
     const size_t lds = Cfg::LOOP_BYTES + 16;
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>), (int)lds);
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG, TERMS>), (int)lds);
     const int tiles = ((max_m + Cfg::BM - 1) / Cfg::BM) * (a.N / Cfg::BN) * (TAG == 1 && a.k_splits > 1 ? a.k_splits : 1);
     int grid = Cfg::WGS * num_cus;
     if (grid > tiles) grid = tiles;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
+    hipLaunchKernelGGL((gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG, TERMS>), dim3(grid), dim3(Cfg::THREADS), lds, s, a);
 }
 
 // CfgC is the default for every GEMM (measured end to end: 5672 docs/s, CfgB 5425, CfgA for the GELU GEMM + CfgB 5283), CfgP for the CLS-probe
@@ -631,6 +634,15 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
         if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }      // Q of the CLS rows (xprobe.hip)
         if (!a.out_split && epi == EPI_TANH) { launch_split_one<CfgP, EPI_TANH, false, false, 1>(a, max_m, num_cus, s); return; }      // dense + tanh of an exit head
         // not a shape the probe launches: the default configuration below computes the same bits
+    }
+    if (a.terms == 1) {      // MMEE_FLAG_ONE_TERM: the four layer GEMMs on one f16 term (a reported low-precision mode; anything else runs the three terms)
+        if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgC, EPI_GELU, true, false, 0, 1>(a, max_m, num_cus, s); return; }
+        if (a.out_split && epi == EPI_BIAS) { launch_split_one<CfgC, EPI_BIAS, true, false, 0, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_RESID) {
+            if (a.role_tag == 3) launch_split_one<CfgC, EPI_RESID, false, false, 3, 1>(a, max_m, num_cus, s);
+            else launch_split_one<CfgC, EPI_RESID, false, false, 2, 1>(a, max_m, num_cus, s);
+            return;
+        }
     }
     if (a.out_split) {
         if (epi == EPI_GELU) launch_split_one<CfgC, EPI_GELU, true>(a, max_m, num_cus, s);

@@ -339,6 +339,8 @@ struct GemmArgs {
     int tile_order;                  // work-queue order inside a group of 8 M-tiles: 0 = M fastest (eight tiles share a W tile back to back),
                                      // 1 = N fastest (the N-tiles of one M-panel follow each other: they share the A panel)
     int prio_mode;                   // 0 none, 1 raise the priority of odd hardware wave slots, 2 of the second half of the grid
+    int terms;                       // split kernel: 1 = ONE f16 MFMA term per MAC (hi x hi only: MMEE_FLAG_ONE_TERM, the reported low-precision
+                                     //   mode, never a parity path); anything else = the three terms of the split precision
     int dbg_noload;                  // diagnostic: skip the in-loop global loads (results are garbage; timing only)
     int* tile_counter;               // work-queue head (device int, zeroed before the launch); null -> static grid stride
     unsigned long long* clk_probe;   // diagnostic (ee_debug_gemm): per workgroup {shader cycles, 100 MHz ticks}; null in the path
@@ -375,6 +377,7 @@ struct AttnArgs {
     const int* qkv_doc_off;          // [n_docs] row offsets of the documents' Q | K | V rows when those are still in the previous stage's
                                      // numbering; null: doc_off
     int q_limit;                     // > 0: only queries < q_limit of every document (the CLS probe asks for the first block)
+    int terms;                       // attention_idx.hip: 1 = one f16 MFMA term per product (MMEE_FLAG_ONE_TERM); else three
 };
 
 // ---------------------------------------------------------------------------------------------------------------

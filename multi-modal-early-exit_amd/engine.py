@@ -186,7 +186,8 @@ class EarlyExitEngine:
                 position_ids=None, thresholds: Optional[Union[float, Sequence[float]]] = None,
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
-                validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None) -> EngineOutput:
+                validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
+                one_term: bool = False) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -238,7 +239,9 @@ class EarlyExitEngine:
             xprobe = self.xprobe_default
         flags = ((capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0) |
                  (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0) |
-                 (capi.FLAG_XPROBE if xprobe else 0))
+                 (capi.FLAG_XPROBE if xprobe else 0) | (capi.FLAG_ONE_TERM if one_term else 0))
+        # one_term: REPORTED low-precision mode (one f16 MFMA term per MAC instead of three in the layer GEMMs and the attention); outside the
+        # 1e-4 bar by construction, exit indices may flip -- bench.py's `lowprec` field, never a result to rely on
         # xprobe: probe-first layers take the CLS context in X space (no Q | K | V for documents that leave); same exits, logits within
         # tolerance, not bit-identical to whole layers
         # whole_layers / probe_always pin how exit layers are scheduled (default: chosen per layer from the last forward's exits)

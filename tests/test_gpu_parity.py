@@ -734,3 +734,27 @@ def test_engine_default_is_the_xspace_probe(pkg, oracle):
     e32 = pkg.EarlyExitEngine(pkg.ModelConfig.tiny(EE_config=dict(exits=[1, 2], encoder_layer_strategy="ramp")), max_docs=2, max_text_len=16)
     assert e32.precision == "fp32" and e32.xprobe_default is False
     e32.close()
+
+
+def test_one_term_mode_is_a_bounded_deviation(pkg, oracle):
+    """MMEE_FLAG_ONE_TERM (the reported low-precision mode: one f16 MFMA term per MAC in the layer GEMMs and the attention) against the
+    base-shape golden vectors: it must really differ from the split precision (it is not the parity path), stay a small deviation (hidden
+    states carry ~11 significant bits through 12 layers), and flip few exits; the default path on the same handle is untouched by it."""
+    g = load_golden("base_cls")
+    cfg = pkg.ModelConfig.base(EE_config=BASE_EE)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
+    eng = _engine(pkg, cfg, W, max_docs=4, T=512, precision="split")
+    args = (docs["input_ids"], docs["attention_mask"], docs["bbox"], docs["pixel_values"])
+    lp = eng.forward(*args, dump_all=True, want_all=True, one_term=True, validate=True)
+    full = eng.forward(*args, dump_all=True, want_all=True, validate=True)
+    np.testing.assert_allclose(_np(full.all_logits), g["logits_store"], rtol=0, atol=LOGIT_TOL)      # the flag leaves nothing behind
+    d = np.abs(_np(lp.all_logits) - g["logits_store"])
+    report_measured("one_term[base goldens]", "max|dlogit| vs reference", float(d.max()))
+    assert np.isfinite(_np(lp.all_logits)).all()
+    assert 1e-5 < d.max() < 0.25 * max(1.0, float(np.abs(g["logits_store"]).max()))
+    conf_ref = oracle.softmax64(g["logits_store"]).max(-1)
+    conf_lp = oracle.softmax64(_np(lp.all_logits).astype(np.float64)).max(-1)
+    report_measured("one_term[base goldens]", "max|d confidence|", float(np.abs(conf_lp - conf_ref).max()))
+    assert np.abs(conf_lp - conf_ref).max() < 0.05
+    eng.close()
