@@ -465,6 +465,10 @@ def main(argv=None):
     sync()
     dt = time.perf_counter() - t0
     layer_of_exit = np.array(list(EXIT_LAYERS) + [cfg.num_hidden_layers])
+    # work and stage populations of the HEADLINE schedule's last step (rounds 1-3 read them behind the K | V-probe A/B below, whose forward
+    # projects Q | K | V for every row: executed_tflops was 3.5 % high)
+    counts = eng.stage_counts()
+    fl = eng.flops()
     # A/B beside the headline (N = 1): the same steps with the K | V probe (exit rows bit-identical to the dump-all rows)
     kv_probe_rate = None
     if world == 1 and a.xprobe and not stub and not a.whole_layers and not strong and not a.thresholds:   # (not in the pinned profile / PMC child runs)
@@ -476,6 +480,19 @@ def main(argv=None):
         kv_probe_rate = a.steps * B / (time.perf_counter() - t1)
         kv_same_exits = bool(torch.equal(o_kv.exit_layer, out.exit_layer))
         kv_dlogit = float((o_kv.logits - out.logits).abs().max())
+    # per-rank view: compute time before the all-gather, documents, mean exit layer (exit depth varies per document, so an uneven
+    # deal is the one thing that can bend the scaling curve)
+    my_ex = gathered[rank::world, cfg.num_labels].cpu().numpy().astype(np.int64) if world > 1 else None
+    if world > 1:
+        dt = pkg.dist.max_over_ranks(dt, device=dev)
+        mine = np.array([t_local[0] * 1e3, float(n_mine), float(layer_of_exit[my_ex].mean()) if len(my_ex) else 0.0])
+        per_rank = np.stack([pkg.dist.broadcast_array(mine, r, device=dev) for r in range(world)])
+    else:
+        per_rank = None
+
+    n_docs = gathered.shape[0]
+    exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
+
     # Reported beside the headline, NEVER as `value` (SURVEY 8d config 2 / BASELINE.md section 4: "bf16 throughput mode reports its measured
     # deviation separately"): the same steps with ONE f16 MFMA term per MAC in the layer GEMMs and the attention (MMEE_FLAG_ONE_TERM)
     lowprec = None
@@ -496,20 +513,6 @@ def main(argv=None):
                    "what": "MMEE_FLAG_ONE_TERM: hi planes only (plain f16 operands, f32 accumulate) in the four layer GEMMs and the attention; "
                            "CLS probes and exit heads keep three terms; same thresholds as the headline run.  Outside the 1e-4 parity bar by "
                            "construction: a measured deviation, not a result"}
-    # per-rank view: compute time before the all-gather, documents, mean exit layer (exit depth varies per document, so an uneven
-    # deal is the one thing that can bend the scaling curve)
-    my_ex = gathered[rank::world, cfg.num_labels].cpu().numpy().astype(np.int64) if world > 1 else None
-    if world > 1:
-        dt = pkg.dist.max_over_ranks(dt, device=dev)
-        mine = np.array([t_local[0] * 1e3, float(n_mine), float(layer_of_exit[my_ex].mean()) if len(my_ex) else 0.0])
-        per_rank = np.stack([pkg.dist.broadcast_array(mine, r, device=dev) for r in range(world)])
-    else:
-        per_rank = None
-
-    n_docs = gathered.shape[0]
-    exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
-    counts = eng.stage_counts()
-    fl = eng.flops()
 
     line = {
         "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world,
@@ -643,7 +646,7 @@ def main(argv=None):
             if not a.xprobe:
                 child.append("--no-xprobe")
             # kernel-name fragments as rocprofv3 prints them
-            ksub = "16>, 1, true, false, 0>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output
+            ksub = "16>, 1, true, false, 0, 3>" if split else "gemm_f32_dma_kernel<1, 0"   # CfgC, EPI_GELU, split output, three terms
             passes = {}
             for name, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
                                ("sq", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"])):

@@ -535,25 +535,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmArgs g) 
 
 template <int EPI, int AMODE>
 static void launch_one_dma(const GemmArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = gemm_f32_lds_bytes();
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma_kernel<EPI, AMODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_f32_dma_kernel<EPI, AMODE>), (int)lds);
     hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 template <int EPI, int AMODE>
 static void launch_one(const GemmArgs& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = gemm_f32_lds_bytes();
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI, AMODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI, AMODE>), (int)lds);
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 

@@ -584,6 +584,15 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
     // what consecutive tickets should share (N fastest): FFN down 402 -> 414 TFLOP/s, attention output unchanged (tools/gemm_split_shapes.py);
     // wider GEMMs keep eight M-tiles per W tile back to back (QKV, FFN up: unchanged to -0.6 % with N fastest)
     a.tile_order = a.N <= 768 ? 1 : 0;
+    // (ahead of the diagnostic library's forced configurations: only these instantiations honour k_splits -- ADVICE r03)
+    if (a.probe) {      // CLS probe: 128 x 128 tiles under their own kernel name; same MFMA form, k order and term order as CfgC => the same bits
+        if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }      // Q of the CLS rows (xprobe.hip)
+        if (!a.out_split && epi == EPI_TANH) { launch_split_one<CfgP, EPI_TANH, false, false, 1>(a, max_m, num_cus, s); return; }      // dense + tanh of an exit head
+        // not a shape the probe launches: the default configuration below computes the same bits
+    }
+    a.k_splits = 1;      // every kernel below writes ONE part
 #ifdef MMEE_DIAG
     static const int order_env = diag_env_int("MMEE_GEMM_ORDER", -1);      // A/B of the queue order: 0 / 1 for every GEMM, 2 = N fastest where N <= 768
     if (order_env == 0 || order_env == 1) a.tile_order = order_env;
@@ -628,13 +637,6 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
         return;
     }
 #endif
-    if (a.probe) {      // CLS probe: 128 x 128 tiles under their own kernel name; same MFMA form, k order and term order as CfgC => the same bits
-        if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
-        if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
-        if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }      // Q of the CLS rows (xprobe.hip)
-        if (!a.out_split && epi == EPI_TANH) { launch_split_one<CfgP, EPI_TANH, false, false, 1>(a, max_m, num_cus, s); return; }      // dense + tanh of an exit head
-        // not a shape the probe launches: the default configuration below computes the same bits
-    }
     if (a.terms == 1) {      // MMEE_FLAG_ONE_TERM: the four layer GEMMs on one f16 term (a reported low-precision mode; anything else runs the three terms)
         if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgC, EPI_GELU, true, false, 0, 1>(a, max_m, num_cus, s); return; }
         if (a.out_split && epi == EPI_BIAS) { launch_split_one<CfgC, EPI_BIAS, true, false, 0, 1>(a, max_m, num_cus, s); return; }

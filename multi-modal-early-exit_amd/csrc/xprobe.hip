@@ -435,11 +435,9 @@ bool xprobe_supports(const XProbeArgs& a, int max_len) {
 
 template <int HEADS, int HH, int RING>
 static void launch_xprobe_attn(const XProbeArgs& a, const XpLayout& L, int grid, hipStream_t s) {
-    static int attr_lds = 0;
-    if (L.lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xprobe_attn_kernel<HEADS, HH, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
-        attr_lds = L.lds;
-    }
+    // per kernel AND device (a process-wide high-water mark left a second device without its opt-in); a failure shows up as the
+    // launch error ee_forward reports
+    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&xprobe_attn_kernel<HEADS, HH, RING>), L.lds);
     hipLaunchKernelGGL((xprobe_attn_kernel<HEADS, HH, RING>), dim3(grid), dim3(XP_THREADS), L.lds, s, a, L.tstr, L.off_tab, L.off_part, L.off_idx, L.npad);
 }
 
