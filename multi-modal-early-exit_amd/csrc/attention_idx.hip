@@ -167,6 +167,9 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // XP: experiment bits kept as template switches while they are being measured (tools/attn_ab.sh, MMEE_ATTN_XP in the diagnostic library):
 //   2 = bias first: the lookups initialise the score accumulator (two adds per score instead of three, no zero init, no mid-tile wait;
 //       the index words of tile kt + 1 are fetched right behind the lookups of tile kt, before the DMA of tile kt + 2),
+//   4 = two ring slots in use instead of three (tile kt + 1 fetched during tile kt, full wait at every tile): round 4, 256 documents x 12
+//       layers, 9.37 / 9.42 ms against 9.41 / 9.42 ms with three slots, results bit-identical -- the third slot buys nothing, but nothing
+//       that was measured needs its 16 KB either (a combined x / y table would: see DESIGN section 5), so the path keeps three,
 // Measured and removed (round 3, tools/attn_ab.sh on 256 documents x 12 layers, baseline 10.1 ms; bias first 9.9 ms): two-item tickets
 // 10.5 ms, eight precomputed V fragment addresses 10.0 ms, software-pipelined tiles (Q K^T of tile kt + 1 paired with the exp / split of
 // tile kt, P V of tile kt with the lookups of tile kt + 1, in one basic block each) 10.1 ms at 168 VGPRs + 18 spilled, K / V DMA and Q
@@ -179,6 +182,8 @@ constexpr int kXP = 2;
 template <int MODE, bool BIAS, int XP, int TERMS = 3>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
+    constexpr bool R2 = (XP & 4) != 0;          // experiment: two ring slots in use, tile kt + 1 fetched during tile kt
+    constexpr int AHEAD = R2 ? 1 : 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
@@ -457,19 +462,20 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         // ---- prologue: tiles 0 and 1 into slots 0 and 1, the index words of tile 0 ----
         issue_any(0, 0u);
         if ((XP & 2) && wave_active && want_idx) issue_idx(0);      // bias first: the index words of a tile are older than the DMA of the tile after it
-        if (n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
+        if (!R2 && n_kt > 1) issue_any(1, (unsigned)STAGE_BYTES);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the table stores have left this wave before it reaches tile 0's barrier
         STAMP(6, tprev)
 
         if (!wave_active) {
             // a wave without queries of this item (the document's last query tile): its share of the DMA and the barriers, nothing else
-            unsigned sb2 = 2u * STAGE_BYTES;
+            unsigned sb2 = R2 ? (unsigned)STAGE_BYTES : 2u * STAGE_BYTES;
             for (int kt = 0; kt < n_kt; ++kt) {
-                if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (!R2 && kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");
-                if (kt + 2 < n_kt) issue_any(kt + 2, sb2);
-                sb2 = sb2 == 2u * STAGE_BYTES ? 0u : sb2 + (unsigned)STAGE_BYTES;
+                if (kt + AHEAD < n_kt) issue_any(kt + AHEAD, sb2);
+                if (R2) sb2 ^= (unsigned)STAGE_BYTES;
+                else sb2 = sb2 == 2u * STAGE_BYTES ? 0u : sb2 + (unsigned)STAGE_BYTES;
             }
             continue;
         }
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         auto tile = [&](auto var_tag, const int kt) __attribute__((always_inline)) {
             constexpr int VAR = decltype(var_tag)::value;
             constexpr bool more1 = VAR != V_LAST, issue2 = VAR == V_HOT || VAR == V_TAIL;
-            const unsigned sb2 = sb == 0u ? 2u * STAGE_BYTES : sb - (unsigned)STAGE_BYTES;
+            const unsigned sb2 = R2 ? (sb ^ (unsigned)STAGE_BYTES) : sb == 0u ? 2u * STAGE_BYTES : sb - (unsigned)STAGE_BYTES;
             // tile kt has landed: everything but the youngest operations -- the four pieces of tile kt + 1 and the four index loads of this
             // tile, issued after them -- is complete; then the barrier: everyone's pieces have, and everyone is done with tile kt - 1,
             // whose slot tile kt + 2 goes into
@@ -489,8 +495,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 if (more1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {      // bias first: the youngest four operations are the pieces of tile kt + 1; this tile's index words are older
-                if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (more1 && !R2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // two-slot ring: this tile's pieces were the youngest
             }
             STAMP(0, tprev)
             if (!(MODE == 2 && (dbg & 64))) asm volatile("s_barrier" ::: "memory");      // 64: no barrier (timing variant: races)
@@ -536,8 +542,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 }
                 if (!(MODE == 2 && (dbg & 128)) && TERMS == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[stp], s, 0, 0, 0);      // 128: no Q K^T MFMAs
                 else asm volatile("" :: "v"(kl), "v"(kh));
-                if (VAR == V_HOT) issue_full(kt + 2, sb2, stp);
-                if (VAR == V_TAIL) issue_tail(kt + 2, sb2, stp);
+                if (VAR == V_HOT) issue_full(kt + AHEAD, sb2, stp);
+                if (VAR == V_TAIL) issue_tail(kt + AHEAD, sb2, stp);
                 if (!(MODE == 2 && (dbg & 128))) {
                     if (TERMS == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[stp], s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[stp], s, 0, 0, 0);
@@ -564,13 +570,14 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             STAMP(2, tprev)
             softmax_pv(s, st, vbase + sb);
             STAMP(4, tprev)
-            sb = sb == 2u * STAGE_BYTES ? 0u : sb + (unsigned)STAGE_BYTES;
+            if (R2) sb ^= (unsigned)STAGE_BYTES;
+            else sb = sb == 2u * STAGE_BYTES ? 0u : sb + (unsigned)STAGE_BYTES;
         };
         {
             int kt = 0;
-            for (; kt + 2 < n_full; ++kt) tile(std::integral_constant<int, V_HOT>{}, kt);           // tile kt + 2 is a whole tile
-            if (kt + 2 < n_kt) { tile(std::integral_constant<int, V_TAIL>{}, kt); ++kt; }            // ... is the partial last tile
-            if (kt + 1 < n_kt) { tile(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
+            for (; kt + AHEAD < n_full; ++kt) tile(std::integral_constant<int, V_HOT>{}, kt);           // tile kt + AHEAD is a whole tile
+            if (kt + AHEAD < n_kt) { tile(std::integral_constant<int, V_TAIL>{}, kt); ++kt; }            // ... is the partial last tile
+            if (!R2 && kt + 1 < n_kt) { tile(std::integral_constant<int, V_PENULT>{}, kt); ++kt; }
             tile(std::integral_constant<int, V_LAST>{}, kt);
         }
 
@@ -660,6 +667,7 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         switch (xp) {
             case 0: launch_idx<true, 0>(a, max_docs, num_cus, stamps, dbg, s); return;
             case 2: launch_idx<true, 2>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 6: launch_idx<true, 6>(a, max_docs, num_cus, stamps, dbg, s); return;
 
             default: break;
         }

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
 
     unsigned long long clk0 = 0, rt0 = 0;
     if (DIAG && g.clk_probe) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    constexpr int GM = 8;
+    constexpr int GM = 8;      // (round 4: 4 is equal on all four layer shapes, 16 is 0-2.5 % slower; tools/gemm_ab.py)
     int* q_slot = reinterpret_cast<int*>(reinterpret_cast<char*>(smem) + Cfg::LOOP_BYTES);
     const int n_groups = (tiles_m + GM - 1) / GM;
     const int my_xcd = g.tile_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
@@ -386,12 +386,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
         t.m0 = __builtin_amdgcn_readfirstlane(tm * BM);
         t.n0 = __builtin_amdgcn_readfirstlane(tn * BN);
         t.kt0 = KSPLIT ? __builtin_amdgcn_readfirstlane(ks_pop * nk) : 0;
-        const int first = g.row_src ? g.row_src[t.m0] : t.m0;
+        int first = g.row_src ? g.row_src[t.m0] : t.m0;
+        if (DIAG && (dbg & 16)) first = 0;
 #pragma unroll
         for (int j = 0; j < PA; ++j) {
             const int piece = wave + Cfg::NW * j;
             int ra = t.m0 + Cfg::PROWS * piece + p_row;
             ra = ra < M ? ra : M - 1;
+            if (DIAG && (dbg & 16)) ra = Cfg::PROWS * piece + p_row;      // timing variant (wrong results): every tile streams A panel 0, an L2-resident A operand
             const int sa = g.row_src ? g.row_src[ra] : ra;
             t.a_voff[j] = (unsigned)(sa - first) * (unsigned)g.lda * 4u + ((piece & 1) ? chunk_odd : chunk_even);
         }
@@ -468,6 +470,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            // (measured, round 4: issuing this DMA behind the MFMAs of the first / second / third W fragment instead costs 1-4 % / 3-8 % / 4-8 % on
+            // the four layer shapes -- the lead of a stage's DMA matters; profiles/r04_gemm_epilogue_experiments.txt section 10)
             if (kt + NST - 1 < nk && !(dbg & 1)) issue(cur, kt + NST - 1, bufn);
             const char* sb = sbytes + buf * STAGE_BYTES;
             if constexpr (Cfg::MF == 16) {
