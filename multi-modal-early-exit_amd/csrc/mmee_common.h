@@ -94,23 +94,43 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+// Sum over the 64 lanes by DPP, returned wave-uniform (through an SGPR): quad xor 1, quad xor 2, row_half_mirror, row_mirror leave the sum of
+// its 16-lane row in every lane (each step adds two lanes that already hold equal partial sums of disjoint lane sets, so both partners
+// compute the same bits); row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 put the total into lane 63.  Six v_add_f32_dpp and
+// one v_readlane instead of six ds_bpermute round trips with their address arithmetic: PMC showed the LayerNorm and embedding kernels bound by
+// VALU issue and LDS-crossbar latency, not by HBM (round 4).  A fixed order, so a fixed result for a given row.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v) {      // lanes in rows outside ROW_MASK read 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    v += dpp_or_zero<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+    v += dpp_or_zero<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+    v += dpp_or_zero<0x141, 0xf>(v);       // row_half_mirror
+    v += dpp_or_zero<0x140, 0xf>(v);       // row_mirror
+    v += dpp_or_zero<0x142, 0xa>(v);       // row_bcast15 -> rows 1, 3
+    v += dpp_or_zero<0x143, 0xc>(v);       // row_bcast31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Row-wise LayerNorm on a row held by one wave: lane owns columns c = 4*lane + 256*i + e (i < NV, e < 4).
-// Two-pass (mean, then centred variance), biased variance, as torch.nn.LayerNorm.
-template <int NV>
+// Two-pass (mean, then centred variance), biased variance, as torch.nn.LayerNorm.  FULL: H == 256 * NV, no column is ever masked (the
+// per-chunk `c < H` tests cost an exec-mask branch and register copies each when H is a run-time value).
+template <int NV, bool FULL = false>
 __device__ __forceinline__ void wave_layernorm(f32x4 (&x)[NV], int H, int lane, const float* __restrict__ gamma,
                                                const float* __restrict__ beta, float eps) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+        if (FULL || c < H) s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
     }
-    const float mean = wave_sum(s) / (float)H;
+    const float mean = wave_sum_uniform(s) / (float)H;
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) {
+        if (FULL || c < H) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = x[i][e] - mean;
@@ -118,11 +138,11 @@ __device__ __forceinline__ void wave_layernorm(f32x4 (&x)[NV], int H, int lane, 
             }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)H + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_uniform(v) / (float)H + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) {
+        if (FULL || c < H) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
@@ -269,14 +289,16 @@ __device__ __forceinline__ void store_split4(void* row_base, int col, const f32x
 // store instruction then writes whole contiguous kilobytes instead of 8-byte pieces 32 bytes apart (the GEMM epilogue's form).  All four
 // lanes of a quad must be active and col must be 4 * lane + a multiple of 16.
 __device__ __forceinline__ void store_split4_quad(void* row_base, int col, const f32x4& v, float scale, float& amax, int lane) {
-    f16x4 hi, lo;
-    split_f16x4(v, scale, hi, lo, amax);
-    const int2 h2 = __builtin_bit_cast(int2, hi), l2 = __builtin_bit_cast(int2, lo);
+    // split_pair: 4 instructions per pair (the GEMM epilogues' form; the same hi / lo bits as split_f16x4 for every value that does not
+    // overflow, and overflow is flagged either way)
+    unsigned h01, l01, h23, l23;
+    split_pair(v[0] * scale, v[1] * scale, h01, l01, amax);
+    split_pair(v[2] * scale, v[3] * scale, h23, l23, amax);
     const bool take_lo = (lane & 2) != 0;
-    const int a0 = __builtin_amdgcn_mov_dpp(h2.x, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp(h2.y, 0x88, 0xf, 0xf, true);
-    const int b0 = __builtin_amdgcn_mov_dpp(l2.x, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp(l2.y, 0x88, 0xf, 0xf, true);
-    const int c0 = __builtin_amdgcn_mov_dpp(h2.x, 0xDD, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp(h2.y, 0xDD, 0xf, 0xf, true);
-    const int d0 = __builtin_amdgcn_mov_dpp(l2.x, 0xDD, 0xf, 0xf, true), d1 = __builtin_amdgcn_mov_dpp(l2.y, 0xDD, 0xf, 0xf, true);
+    const int a0 = __builtin_amdgcn_mov_dpp((int)h01, 0x88, 0xf, 0xf, true), a1 = __builtin_amdgcn_mov_dpp((int)h23, 0x88, 0xf, 0xf, true);
+    const int b0 = __builtin_amdgcn_mov_dpp((int)l01, 0x88, 0xf, 0xf, true), b1 = __builtin_amdgcn_mov_dpp((int)l23, 0x88, 0xf, 0xf, true);
+    const int c0 = __builtin_amdgcn_mov_dpp((int)h01, 0xDD, 0xf, 0xf, true), c1 = __builtin_amdgcn_mov_dpp((int)h23, 0xDD, 0xf, 0xf, true);
+    const int d0 = __builtin_amdgcn_mov_dpp((int)l01, 0xDD, 0xf, 0xf, true), d1 = __builtin_amdgcn_mov_dpp((int)l23, 0xDD, 0xf, 0xf, true);
     int4 piece;
     piece.x = take_lo ? b0 : a0;
     piece.y = take_lo ? b1 : a1;

@@ -160,22 +160,22 @@ __global__ __launch_bounds__(256) void row_meta_kernel(PrepArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NV>
+template <int NV, bool FULL = false>
 __device__ __forceinline__ void wave_store_row(float* __restrict__ dst, const f32x4 (&x)[NV], int H, int lane) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) *reinterpret_cast<f32x4*>(dst + c) = x[i];
+        if (FULL || c < H) *reinterpret_cast<f32x4*>(dst + c) = x[i];
     }
 }
 
 // the same row as split-f16 planes (the A operand of the first Q|K|V projection, the residual of the first attention output)
-template <int NV>
+template <int NV, bool FULL = false>
 __device__ __forceinline__ void wave_store_row_split(void* dst_row, const f32x4 (&x)[NV], int H, int lane, float scale, float& amax) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < H) store_split4_quad(dst_row, c, x[i], scale, amax, lane);      // split rows exist only where H % 256 == 0: whole waves take the branch
+        if (FULL || c < H) store_split4_quad(dst_row, c, x[i], scale, amax, lane);      // split rows exist only where H % 256 == 0: whole waves take the branch
     }
 }
 
@@ -193,7 +193,7 @@ __device__ __forceinline__ void block_write_partial(float* lds, float* __restric
     for (int c = threadIdx.x; c < H; c += 256) dst[c] = (lds[c] + lds[H + c]) + (lds[2 * H + c] + lds[3 * H + c]);
 }
 
-template <int NV, bool FAST, bool POOLED>
+template <int NV, bool FAST, bool POOLED, bool FULL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void embed_text_kernel(EmbedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int T = a.T, H = a.H;
@@ -207,10 +207,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int doff = a.doc_off[b];
     constexpr bool pooled = POOLED;                           // the pooled embedding exits (text_part / cat_part) average over every position, padding included
     float amax = 0.f;
-    // The kernel is bound by memory latency, not traffic: per position, ids -> table rows -> two LayerNorms -> store, and a wave walks
-    // its 8 positions in turn.  So (1) lane t fetches the ids / box / position of the wave's position t, all 8 at once, and the loop
-    // reads them back with v_readlane; (2) the table rows of position t + 1 are in flight while position t is normalised; (3) the
-    // registers stay few (no unrolling over positions, branch-free addressing of the spatial tables): many waves per SIMD.
+    // Per position: ids -> table rows -> two LayerNorms -> store, and a wave walks its 8 positions in turn.  (1) Lane t fetches the ids /
+    // box / position of the wave's position t, all 8 at once, and the loop reads them back with v_readlane; (2) the registers stay few (no
+    // unrolling over positions, branch-free addressing of the spatial tables): many waves per SIMD.  Round 4 (PMC: 134 M VALU instructions per
+    // launch = 0.5 ms of VALU issue, SQ_WAIT_ANY 73 % of the wave cycles): the software prefetch of position t + 1's rows is gone (114 -> 80
+    // VGPRs, 0.93 -> 0.78 ms), the reductions are DPP and the `c < H` tests compile away when H == 256 NV.
     const int j0 = ch * 32 + wave * 8;
     int m_id = 0, m_tt = 0, m_pid = 0, m_dst = -1, m_b0 = 0, m_b1 = 0, m_b2 = 0, m_b3 = 0;
     if (lane < 8 && j0 + lane < T) {
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
-            if (c < H) {
+            if (FULL || c < H) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(a.word + (size_t)id * H + c);
                 v += *reinterpret_cast<const f32x4*>(a.type + (size_t)tt * H + c);
                 v += *reinterpret_cast<const f32x4*>(a.pos + (size_t)pid * H + c);
@@ -289,33 +290,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     };
     // a padded position has no packed row; it is embedded only when a pooled exit averages over it
     auto wanted = [&](int t) __attribute__((always_inline)) { return j0 + t < T && (pooled || __builtin_amdgcn_readlane(m_dst, t) >= 0); };
-    f32x4 xn[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) xn[i] = f32x4{0, 0, 0, 0};
-    if (wanted(0)) load_row(0, xn);
     // not unrolled: eight positions' worth of rows in registers is one wave per SIMD, and this kernel lives on occupancy
 #pragma unroll 1
     for (int t = 0; t < 8; ++t) {
         const bool want = wanted(t);                          // wave-uniform
         f32x4 x[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) x[i] = xn[i];
-        if (t + 1 < 8 && wanted(t + 1)) load_row(t + 1, xn);
         if (!want) continue;
+        load_row(t, x);
         const int dst = __builtin_amdgcn_readlane(m_dst, t);
-        wave_layernorm<NV>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // embeddings.LayerNorm
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // embeddings.LayerNorm
         if constexpr (POOLED) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) acc_t[i] += x[i];
         }
-        wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);      // layoutlmv3.LayerNorm (after the concat)
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);      // layoutlmv3.LayerNorm (after the concat)
         if constexpr (POOLED) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
         }
         if (dst >= 0) {
-            if (a.Xs) wave_store_row_split<NV>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + dst) * H * 4, x, H, lane, a.split_scale, amax);
-            else wave_store_row<NV>(a.X + (size_t)(doff + dst) * H, x, H, lane);
+            if (a.Xs) wave_store_row_split<NV, FULL>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + dst) * H * 4, x, H, lane, a.split_scale, amax);
+            else wave_store_row<NV, FULL>(a.X + (size_t)(doff + dst) * H, x, H, lane);
         }
     }
     if (a.Xs) split_flag_overflow(amax, a.err_flag);
@@ -325,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
-template <int NV>
+template <int NV, bool FULL = false>
 __global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = a.H, Pv = a.Pv;
@@ -345,7 +340,7 @@ __global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
-            if (c < H) {
+            if (FULL || c < H) {
                 f32x4 e = (v == 0) ? *reinterpret_cast<const f32x4*>(a.cls_token + c)
                                    : *reinterpret_cast<const f32x4*>(a.vis_raw + ((size_t)b * (Pv - 1) + (v - 1)) * H + c);
                 x[i] = e + *reinterpret_cast<const f32x4*>(a.pos_embed + (size_t)v * H + c);
@@ -353,18 +348,53 @@ __global__ __launch_bounds__(256) void embed_visual_kernel(EmbedArgs a) {
                 x[i] = f32x4{0, 0, 0, 0};
             }
         }
-        wave_layernorm<NV>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // layoutlmv3.norm, eps 1e-6
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // layoutlmv3.norm, eps 1e-6
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc_v[i] += x[i];
-        wave_layernorm<NV>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc_c[i] += x[i];
-        if (a.Xs) wave_store_row_split<NV>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + v) * H * 4, x, H, lane, a.split_scale, amax);
-        else wave_store_row<NV>(a.X + (size_t)(doff + v) * H, x, H, lane);
+        if (a.Xs) wave_store_row_split<NV, FULL>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + v) * H * 4, x, H, lane, a.split_scale, amax);
+        else wave_store_row<NV, FULL>(a.X + (size_t)(doff + v) * H, x, H, lane);
     }
     if (a.Xs) split_flag_overflow(amax, a.err_flag);
     if (a.vis_part) block_write_partial<NV>(lds, a.vis_part + ((size_t)b * nch + ch) * H, acc_v, H, lane, wave);
     if (a.cat_part) block_write_partial<NV>(lds, a.cat_part + ((size_t)b * a.cat_chunks + tch + ch) * H, acc_c, H, lane, wave);
+}
+
+// The same rows without the pooled-exit partial sums (no embedding-level exit configured: nothing needs a fixed row -> workgroup assignment):
+// one row per wave and iteration, grid-stride, as ln_rows_kernel.  Per row the arithmetic is the kernel's above, so are the bits.
+// Round 4, B = 1024: 0.47 ms (the kernel above: 8 rows per wave in turn, 120 VGPRs) -> 0.39 ms with 4096 workgroups (0.41 with 2048; forcing
+// 64 VGPRs spilled: 0.69 ms) -> 0.30 ms with the DPP reductions, the 4-instruction split and FULL (66 VGPRs, 632 -> 422 VALU instructions)
+// -> 0.275 ms with 8192 workgroups (16384: 0.271).
+template <int NV, bool FULL = false>
+__global__ __launch_bounds__(256) void embed_visual_rows_kernel(EmbedArgs a) {
+    const int H = a.H, Pv = a.Pv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_rows = a.B * Pv;
+    float amax = 0.f;
+#pragma unroll 1
+    for (int r = blockIdx.x * 4 + wave; r < n_rows; r += gridDim.x * 4) {
+        const int b = r / Pv, v = r - b * Pv;
+        const int doff = a.doc_off[b] + a.ntext[b];
+        f32x4 x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * lane + 256 * i;
+            if (FULL || c < H) {
+                f32x4 e = (v == 0) ? *reinterpret_cast<const f32x4*>(a.cls_token + c)
+                                   : *reinterpret_cast<const f32x4*>(a.vis_raw + ((size_t)b * (Pv - 1) + (v - 1)) * H + c);
+                x[i] = e + *reinterpret_cast<const f32x4*>(a.pos_embed + (size_t)v * H + c);
+            } else {
+                x[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln1_g, a.ln1_b, a.eps1);      // layoutlmv3.norm, eps 1e-6
+        wave_layernorm<NV, FULL>(x, H, lane, a.ln2_g, a.ln2_b, a.eps2);
+        if (a.Xs) wave_store_row_split<NV, FULL>(reinterpret_cast<char*>(a.Xs) + (size_t)(doff + v) * H * 4, x, H, lane, a.split_scale, amax);
+        else wave_store_row<NV, FULL>(a.X + (size_t)(doff + v) * H, x, H, lane);
+    }
+    if (a.Xs) split_flag_overflow(amax, a.err_flag);
 }
 
 // pooled[b][c] = (sum over chunks, in chunk order) / count      (x.mean(1), EE/models/LayoutLMv3.py:466, 520, 582)
@@ -389,7 +419,7 @@ struct LnPre {
     const char* resid;
     float resid_inv;
 };
-template <int NV, bool PRE>      // PRE is a separate instantiation: the layers' own LayerNorm launches carry none of its code
+template <int NV, bool PRE, bool FULL = false>      // PRE is a separate instantiation: the layers' own LayerNorm launches carry none of its code
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
@@ -403,26 +433,26 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
-            x[i] = (c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
+            x[i] = (FULL || c < H) ? *reinterpret_cast<const f32x4*>(p + c) : f32x4{0, 0, 0, 0};
         }
         if constexpr (PRE) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < H) {
+                if (FULL || c < H) {
                     for (int q = 1; q < pre.n_parts; ++q) x[i] += *reinterpret_cast<const f32x4*>(p + (size_t)q * pre.part_stride + c);
                     if (pre.bias) x[i] += *reinterpret_cast<const f32x4*>(pre.bias + c);
                     if (pre.resid) x[i] += load_split4(pre.resid + (size_t)r * H * 4, c, pre.resid_inv);
                 }
             }
         }
-        wave_layernorm<NV>(x, H, lane, g, b, eps);
-        if (dst) wave_store_row<NV>(dst + (size_t)r * H, x, H, lane);
+        wave_layernorm<NV, FULL>(x, H, lane, g, b, eps);
+        if (dst) wave_store_row<NV, FULL>(dst + (size_t)r * H, x, H, lane);
         if (dst_split) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = 4 * lane + 256 * i;
-                if (c < H) store_split4_quad(dst_split + (size_t)r * H * 4, c, x[i], split_scale, amax, lane);
+                if (FULL || c < H) store_split4_quad(dst_split + (size_t)r * H * 4, c, x[i], split_scale, amax, lane);
             }
         }
     }
@@ -498,31 +528,56 @@ void launch_embed_text(const EmbedArgs& a, hipStream_t s) {
     const int nv = (a.H + 255) / 256;
     const bool fast = (a.cs & 3) == 0 && (a.ss & 3) == 0;
     const bool pooled = a.text_part || a.cat_part;
+    const bool full = a.H == 256 * nv;      // every column chunk is whole: the kernels' `c < H` tests compile away
 #define MMEE_ET(NV_, F_, P_) hipLaunchKernelGGL((embed_text_kernel<NV_, F_, P_>), dim3(grid), dim3(256), lds, s, a)
+#define MMEE_ETF(NV_, P_) hipLaunchKernelGGL((embed_text_kernel<NV_, true, P_, true>), dim3(grid), dim3(256), lds, s, a)
     switch (nv) {
         case 1: MMEE_ET(1, false, true); break;      // tiny test models
         case 2: MMEE_ET(2, false, true); break;
         case 3:
-            if (fast && pooled) MMEE_ET(3, true, true); else if (fast) MMEE_ET(3, true, false);
+            if (fast && full) { if (pooled) MMEE_ETF(3, true); else MMEE_ETF(3, false); }
+            else if (fast && pooled) MMEE_ET(3, true, true); else if (fast) MMEE_ET(3, true, false);
             else if (pooled) MMEE_ET(3, false, true); else MMEE_ET(3, false, false);
             break;
         default:
-            if (fast && pooled) MMEE_ET(4, true, true); else if (fast) MMEE_ET(4, true, false);
+            if (fast && full) { if (pooled) MMEE_ETF(4, true); else MMEE_ETF(4, false); }
+            else if (fast && pooled) MMEE_ET(4, true, true); else if (fast) MMEE_ET(4, true, false);
             else if (pooled) MMEE_ET(4, false, true); else MMEE_ET(4, false, false);
             break;
     }
 #undef MMEE_ET
+#undef MMEE_ETF
 }
 
 void launch_embed_visual(const EmbedArgs& a, hipStream_t s) {
+    const int nv = (a.H + 255) / 256;
+    const bool full = a.H == 256 * nv;
+    if (!a.vis_part && !a.cat_part) {          // no pooled embedding exit: rows in any order
+        int g = (a.B * a.Pv + 3) / 4;
+        if (g > 8192) g = 8192;
+        switch (nv) {
+            case 1: hipLaunchKernelGGL(embed_visual_rows_kernel<1>, dim3(g), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(embed_visual_rows_kernel<2>, dim3(g), dim3(256), 0, s, a); break;
+            case 3: if (full) hipLaunchKernelGGL((embed_visual_rows_kernel<3, true>), dim3(g), dim3(256), 0, s, a);
+                    else hipLaunchKernelGGL(embed_visual_rows_kernel<3>, dim3(g), dim3(256), 0, s, a);
+                    break;
+            default: if (full) hipLaunchKernelGGL((embed_visual_rows_kernel<4, true>), dim3(g), dim3(256), 0, s, a);
+                     else hipLaunchKernelGGL(embed_visual_rows_kernel<4>, dim3(g), dim3(256), 0, s, a);
+                     break;
+        }
+        return;
+    }
     const int grid = a.B * ((a.Pv + 31) / 32);
     const size_t lds = 4 * (size_t)a.H * sizeof(float);
-    const int nv = (a.H + 255) / 256;
     switch (nv) {
         case 1: hipLaunchKernelGGL(embed_visual_kernel<1>, dim3(grid), dim3(256), lds, s, a); break;
         case 2: hipLaunchKernelGGL(embed_visual_kernel<2>, dim3(grid), dim3(256), lds, s, a); break;
-        case 3: hipLaunchKernelGGL(embed_visual_kernel<3>, dim3(grid), dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL(embed_visual_kernel<4>, dim3(grid), dim3(256), lds, s, a); break;
+        case 3: if (full) hipLaunchKernelGGL((embed_visual_kernel<3, true>), dim3(grid), dim3(256), lds, s, a);
+                else hipLaunchKernelGGL(embed_visual_kernel<3>, dim3(grid), dim3(256), lds, s, a);
+                break;
+        default: if (full) hipLaunchKernelGGL((embed_visual_kernel<4, true>), dim3(grid), dim3(256), lds, s, a);
+                 else hipLaunchKernelGGL(embed_visual_kernel<4>, dim3(grid), dim3(256), lds, s, a);
+                 break;
     }
 }
 
@@ -540,12 +595,16 @@ void launch_ln_rows(const float* src, float* dst, const int* row_src, const int*
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     const int nv = (H + 255) / 256;
+    const bool full = H == 256 * nv;
+#define MMEE_LN(NV_, PRE_, FULL_) hipLaunchKernelGGL((ln_rows_kernel<NV_, PRE_, FULL_>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre)
+    const bool has_pre = pre.n_parts > 0;
     switch (nv) {
-        case 1: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<1, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<1, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
-        case 2: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<2, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
-        case 3: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<3, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<3, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
-        default: if (pre.n_parts > 0) hipLaunchKernelGGL((ln_rows_kernel<4, true>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); else hipLaunchKernelGGL((ln_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, src, dst, row_src, n_rows_ptr, H, g, b, eps, dst_split, split_scale, err_flag, pre); break;
+        case 1: if (has_pre) MMEE_LN(1, true, false); else if (full) MMEE_LN(1, false, true); else MMEE_LN(1, false, false); break;
+        case 2: if (has_pre) MMEE_LN(2, true, false); else MMEE_LN(2, false, false); break;
+        case 3: if (has_pre) { if (full) MMEE_LN(3, true, true); else MMEE_LN(3, true, false); } else if (full) MMEE_LN(3, false, true); else MMEE_LN(3, false, false); break;
+        default: if (has_pre) { if (full) MMEE_LN(4, true, true); else MMEE_LN(4, true, false); } else if (full) MMEE_LN(4, false, true); else MMEE_LN(4, false, false); break;
     }
+#undef MMEE_LN
 }
 
 void launch_embed_beit(const float* patch, const float* cls, const float* pos, int B, int Pv, int H, float* X, hipStream_t s) {
