@@ -169,7 +169,10 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 //       the index words of tile kt + 1 are fetched right behind the lookups of tile kt, before the DMA of tile kt + 2),
 //   4 = two ring slots in use instead of three (tile kt + 1 fetched during tile kt, full wait at every tile): round 4, 256 documents x 12
 //       layers, 9.37 / 9.42 ms against 9.41 / 9.42 ms with three slots, results bit-identical -- the third slot buys nothing, but nothing
-//       that was measured needs its 16 KB either (a combined x / y table would: see DESIGN section 5), so the path keeps three,
+//       that was measured needs its 16 KB either, so the path keeps three.  What the 16 KB was tried for: ONE lookup for rel_pos_x +
+//       rel_pos_y in a [bins2 x bins2] table of pre-rounded sums living in the third slot (fetched per head by four LDS-DMA pieces per wave,
+//       pair index carrying bx * bins2 + by; logits bit-identical) -- 10.63 ms against 9.40 ms: the 4096-entry gathers conflict ~3.5-way
+//       where the 64-entry tables are at most 2-way, and the LDS, not the 32 VALU instructions saved, sets the pace.  Removed,
 // Measured and removed (round 3, tools/attn_ab.sh on 256 documents x 12 layers, baseline 10.1 ms; bias first 9.9 ms): two-item tickets
 // 10.5 ms, eight precomputed V fragment addresses 10.0 ms, software-pipelined tiles (Q K^T of tile kt + 1 paired with the exp / split of
 // tile kt, P V of tile kt with the lookups of tile kt + 1, in one basic block each) 10.1 ms at 168 VGPRs + 18 spilled, K / V DMA and Q
