@@ -176,6 +176,13 @@ int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int3
  * plan of a warm-up forward (ee_last_layer_plan: docs_probe[l] > 0) so that every measured step runs the same launches. */
 int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask);
 
+/* `inputs_embeds` of the reference signature (EE/models/LayoutLMv3.py:383, 414-417 -> LayoutLMv3TextEmbeddings.forward, HF:185-186:
+ * "if inputs_embeds is None: inputs_embeds = self.word_embeddings(input_ids)").  embeds: dev float (B,T,H) of the NEXT ee_forward call, read
+ * in place of the word-embedding rows; consumed by that call (pass it again for the next one), NULL clears it.  ee_forward still takes
+ * input_ids -- validated and used for the default, padding-aware position ids; a caller without token ids passes pad-free dummies (any valid
+ * id != pad_token_id) together with the sequential position_ids of HF:148-158 (pad_token_id + 1 + t), which is what the host mirror does. */
+int ee_set_inputs_embeds(ee_handle* h, const float* embeds);
+
 /*
  * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]
  * (global threshold: repeat it).  exits dev int32 (N,), predictions dev double (N,K), confidence dev double (N,) or

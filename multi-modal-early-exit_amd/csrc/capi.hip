@@ -124,6 +124,7 @@ struct ee_handle {
     uint32_t last_flags = 0;
     bool last_gate_heads = true;                  // gate strategy: were the 2-way gate heads evaluated in the last forward
     bool mask_on = false;                         // ee_set_probe_mask: the exit-layer schedule is pinned
+    const float* next_inputs_embeds = nullptr;    // ee_set_inputs_embeds: read by the next ee_forward, then cleared
     uint64_t probe_mask = 0;
 };
 
@@ -867,6 +868,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     ea.emb_pos = h->emb_pos; ea.text_dst = h->text_dst; ea.ntext = h->ntext; ea.doc_off = S_doc_off(0);
     ea.B = B; ea.T = T; ea.Pv = Pv; ea.H = H; ea.cs = c.coordinate_size; ea.ss = c.shape_size; ea.max_2d = c.max_2d_position_embeddings;
     ea.vocab = c.vocab_size; ea.type_vocab = c.type_vocab_size;
+    ea.inputs_embeds = beit ? nullptr : h->next_inputs_embeds;
+    h->next_inputs_embeds = nullptr;
     ea.word = h->word; ea.type = h->type; ea.pos = h->pos; ea.xtab = h->xtab; ea.ytab = h->ytab; ea.htab = h->htab; ea.wtab = h->wtab;
     ea.ln1_g = h->emb_g; ea.ln1_b = h->emb_b; ea.eps1 = c.layer_norm_eps;
     ea.ln2_g = h->ln_g; ea.ln2_b = h->ln_b; ea.eps2 = c.layer_norm_eps;
@@ -1354,6 +1357,13 @@ int ee_last_stage_counts(ee_handle* h, int32_t* docs_out, int32_t* rows_out, int
         if (rows_out) rows_out[i] = sc[h->exit_stage[i]].n_rows;
     }
     return report_errors(h, err, "a forward since the last check");
+}
+
+int ee_set_inputs_embeds(ee_handle* h, const float* embeds) {
+    if (!h) return 1;
+    if (embeds && h->cfg.arch == MMEE_ARCH_BEIT) return fail(h, "ee_set_inputs_embeds: an image-only model has no text embeddings");
+    h->next_inputs_embeds = embeds;
+    return 0;
 }
 
 int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask) {

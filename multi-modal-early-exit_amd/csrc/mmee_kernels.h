@@ -35,6 +35,7 @@ struct EmbedArgs {
     const int* doc_off;
     int B, T, Pv, H, cs, ss, max_2d, vocab, type_vocab;
     const float *word, *type, *pos, *xtab, *ytab, *htab, *wtab;
+    const float* inputs_embeds;      // (B,T,H) or null: read in place of word[input_ids] (ee_set_inputs_embeds)
     const float *ln1_g, *ln1_b;      // text: embeddings.LayerNorm; visual: layoutlmv3.norm
     float eps1;
     const float *ln2_g, *ln2_b;      // layoutlmv3.LayerNorm

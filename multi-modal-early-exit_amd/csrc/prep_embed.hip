@@ -251,13 +251,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const int id = __builtin_amdgcn_readlane(m_id, t), tt = __builtin_amdgcn_readlane(m_tt, t), pid = __builtin_amdgcn_readlane(m_pid, t);
         const int b0 = __builtin_amdgcn_readlane(m_b0, t), b1 = __builtin_amdgcn_readlane(m_b1, t);
         const int b2 = __builtin_amdgcn_readlane(m_b2, t), b3 = __builtin_amdgcn_readlane(m_b3, t);
+        // the token's word row, or its row of the caller's inputs_embeds (HF:185-186)
+        const float* wrow = a.inputs_embeds ? a.inputs_embeds + ((size_t)b * T + j0 + t) * H : a.word + (size_t)id * H;
         int hidx = b3 - b1; hidx = hidx < 0 ? 0 : (hidx > hi ? hi : hidx);   // clip(y1 - y0, 0, 1023) HF:121
         int widx = b2 - b0; widx = widx < 0 ? 0 : (widx > hi ? hi : widx);   // clip(x1 - x0, 0, 1023) HF:122
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 4 * lane + 256 * i;
             if (FULL || c < H) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(a.word + (size_t)id * H + c);
+                f32x4 v = *reinterpret_cast<const f32x4*>(wrow + c);
                 v += *reinterpret_cast<const f32x4*>(a.type + (size_t)tt * H + c);
                 v += *reinterpret_cast<const f32x4*>(a.pos + (size_t)pid * H + c);
                 f32x4 sp;

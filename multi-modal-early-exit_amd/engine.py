@@ -187,7 +187,7 @@ class EarlyExitEngine:
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
-                one_term: bool = False) -> EngineOutput:
+                one_term: bool = False, inputs_embeds=None) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -198,8 +198,24 @@ class EarlyExitEngine:
             if tuple(px.shape) != (B, self.cfg.num_channels, R, R):
                 raise ValueError(f"pixel_values must be (B,{self.cfg.num_channels},{R},{R})")
         else:
+            emb = None
+            if inputs_embeds is not None:
+                # EE/models/LayoutLMv3.py:414-417 -> HF:160-199: the rows replace word_embeddings(input_ids).  Without input_ids the position
+                # ids are the sequential ones of HF:148-158 (nothing says which position is padding); the C-ABI still wants token ids for
+                # its validation, so it gets pad-free dummies.  With BOTH, HF takes the position ids from input_ids and the rows from here.
+                emb = self._dev(inputs_embeds, torch.float32, "inputs_embeds")
+                if emb.dim() != 3 or emb.shape[2] != self.cfg.hidden_size:
+                    raise ValueError(f"inputs_embeds must be (B,T,{self.cfg.hidden_size})")
+                if input_ids is None:
+                    Bq, Tq = emb.shape[:2]
+                    pad = self.cfg.pad_token_id
+                    input_ids = torch.full((Bq, Tq), 0 if pad != 0 else 1, dtype=torch.int64, device=self.device)
+                    if position_ids is None:
+                        position_ids = torch.arange(pad + 1, Tq + pad + 1, dtype=torch.int64, device=self.device).unsqueeze(0).expand(Bq, Tq)
             ids = self._dev(input_ids, torch.int64, "input_ids")
             B, T = ids.shape
+            if emb is not None and tuple(emb.shape[:2]) != (B, T):
+                raise ValueError("inputs_embeds and input_ids disagree on (B,T)")
             if bbox is None:
                 bbox = torch.zeros((B, T, 4), dtype=torch.int64, device=self.device)   # EE/models/LayoutLMv3.py:433-436
             am = self._dev(attention_mask, torch.int64, "attention_mask", required=False)
@@ -248,11 +264,13 @@ class EarlyExitEngine:
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            if not self.beit and emb is not None:
+                capi.check(self.lib.ee_set_inputs_embeds(self._h, p(emb)), self._h, "ee_set_inputs_embeds")
             rc = self.lib.ee_forward(self._h, p(ids), p(am), p(bb), p(px), p(tt), p(ps), B, T, thr_c, tmp_c, flags,
                                      p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
                                      p(head_logits), p(head_crit), p(hidden), stream)
         capi.check(rc, self._h, "ee_forward")
-        self._keepalive = (ids, am, bb, px, tt, ps)   # borrowed by the enqueued kernels until the stream drains
+        self._keepalive = (ids, am, bb, px, tt, ps, None if self.beit else emb)   # borrowed by the enqueued kernels until the stream drains
         if validate:
             self.stage_counts()                        # synchronises; raises on out-of-range inputs
         return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden)

@@ -151,8 +151,7 @@ class LayoutLMv3EEForSequenceClassification:
 
     # ---- chunked engine call -------------------------------------------------------------------------------------------
     def _run(self, tensors: Dict[str, Any], **kw) -> EngineOutput:
-        ids = tensors["input_ids"]
-        B = ids.shape[0]
+        B = tensors["pixel_values"].shape[0]
         mb = self.engine.max_docs
         if B <= mb:
             return self.engine.forward(**tensors, **kw)
@@ -170,16 +169,18 @@ class LayoutLMv3EEForSequenceClassification:
     def forward(self, input_ids=None, attention_mask=None, bbox=None, pixel_values=None, labels=None,
                 token_type_ids=None, position_ids=None, head_mask=None, inputs_embeds=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, **kwargs) -> EESequenceClassifierOutput:
-        if input_ids is None or pixel_values is None:
-            raise ValueError("the HIP path implements the multimodal evaluation input: input_ids AND pixel_values "
-                             "(EE/utils.py:93-98); inputs_embeds / text-only / image-only calls are not built")
-        if inputs_embeds is not None or head_mask is not None:
-            raise NotImplementedError("inputs_embeds / head_mask are not part of the evaluation hot path")
+        if (input_ids is None and inputs_embeds is None) or pixel_values is None:
+            # (the reference's own forward cannot run these either: with pixel_values=None `visual_embeddings` is unbound at
+            # EE/models/LayoutLMv3.py:550, with neither input_ids nor inputs_embeds `embedding_output` is at :565)
+            raise ValueError("the HIP path implements the multimodal evaluation input: input_ids (or inputs_embeds) AND pixel_values "
+                             "(EE/utils.py:93-98); text-only / image-only calls are not built")
+        if head_mask is not None:
+            raise NotImplementedError("head_mask is not part of the evaluation hot path")
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / full hidden states are never materialised by the fused kernels; "
                                       "EarlyExitEngine.forward(want_hidden_cls=True) returns the CLS row of every layer")
         out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
-                             token_type_ids=token_type_ids, position_ids=position_ids),
+                             token_type_ids=token_type_ids, position_ids=position_ids, inputs_embeds=inputs_embeds),
                         dump_all=True, want_all=True, want_head=True, validate=True)
         return self._pack(out, labels, return_dict)
 

@@ -147,14 +147,20 @@ def position_ids_from_input_ids(input_ids: np.ndarray, pad: int) -> np.ndarray:
     return np.cumsum(m, axis=1) * m + pad
 
 
-def text_embeddings(cfg, W, input_ids, bbox, token_type_ids=None, position_ids=None) -> np.ndarray:
-    """A2 — HF:160-199 (+ HF:112-136 spatial concat), LayerNorm eps = layer_norm_eps."""
+def text_embeddings(cfg, W, input_ids, bbox, token_type_ids=None, position_ids=None, inputs_embeds=None) -> np.ndarray:
+    """A2 — HF:160-199 (+ HF:112-136 spatial concat), LayerNorm eps = layer_norm_eps.  ``inputs_embeds`` (B,T,H) replaces the word rows
+    (HF:185-186); without ``input_ids`` the default position ids are the sequential ones of HF:148-158, 174-175."""
     p = "layoutlmv3.embeddings."
     if position_ids is None:
-        position_ids = position_ids_from_input_ids(input_ids, cfg.pad_token_id)
+        if input_ids is not None:
+            position_ids = position_ids_from_input_ids(input_ids, cfg.pad_token_id)
+        else:
+            Bq, Tq = inputs_embeds.shape[:2]
+            position_ids = np.broadcast_to(np.arange(cfg.pad_token_id + 1, Tq + cfg.pad_token_id + 1, dtype=np.int64)[None], (Bq, Tq))
     if token_type_ids is None:
-        token_type_ids = np.zeros_like(input_ids)
-    e = W[p + "word_embeddings.weight"][input_ids] + W[p + "token_type_embeddings.weight"][token_type_ids]
+        token_type_ids = np.zeros(position_ids.shape, dtype=np.int64)
+    we = W[p + "word_embeddings.weight"][input_ids] if inputs_embeds is None else np.asarray(inputs_embeds, dtype=F32)
+    e = we + W[p + "token_type_embeddings.weight"][token_type_ids]
     e = e + W[p + "position_embeddings.weight"][position_ids]
     X, Y = W[p + "x_position_embeddings.weight"], W[p + "y_position_embeddings.weight"]
     Hh, Ww = W[p + "h_position_embeddings.weight"], W[p + "w_position_embeddings.weight"]
@@ -242,9 +248,12 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
                                               exit_states[j][0] for ramps, final logits last
     """
     p = "layoutlmv3."
-    ids, bbox, pix = batch["input_ids"], batch["bbox"], batch["pixel_values"]
+    ids, bbox, pix = batch.get("input_ids"), batch.get("bbox"), batch["pixel_values"]
     am = batch.get("attention_mask")
-    B, T = ids.shape
+    emb_in = batch.get("inputs_embeds")                                         # :414-417
+    B, T = ids.shape if ids is not None else emb_in.shape[:2]
+    if bbox is None:
+        bbox = np.zeros((B, T, 4), dtype=np.int64)                              # :433-436
     if am is None:
         am = np.ones((B, T), dtype=np.int64)
     emb_exits, enc_exits = split_exits(exits)
@@ -257,7 +266,7 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
     if "vision_avg" in emb_exits:                                               # :465-483
         xin = vis.mean(axis=1, dtype=F32)
         ex_logits.append(exit_head(xin, W, p + _EMB_HEAD["vision_avg"])); gate_inputs.append(xin)
-    txt = text_embeddings(cfg, W, ids, bbox, batch.get("token_type_ids"), batch.get("position_ids"))   # :511-517
+    txt = text_embeddings(cfg, W, ids, bbox, batch.get("token_type_ids"), batch.get("position_ids"), emb_in)   # :511-517
     if "text_avg" in emb_exits:                                                 # :519-534
         xin = txt.mean(axis=1, dtype=F32)
         ex_logits.append(exit_head(xin, W, p + _EMB_HEAD["text_avg"])); gate_inputs.append(xin)

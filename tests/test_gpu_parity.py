@@ -758,3 +758,50 @@ def test_one_term_mode_is_a_bounded_deviation(pkg, oracle):
     report_measured("one_term[base goldens]", "max|d confidence|", float(np.abs(conf_lp - conf_ref).max()))
     assert np.abs(conf_lp - conf_ref).max() < 0.05
     eng.close()
+
+
+@pytest.mark.gpu
+def test_inputs_embeds_vs_oracle_and_vs_input_ids(pkg, oracle):
+    """`inputs_embeds` of the reference signature (EE/models/LayoutLMv3.py:383, 414-417; HF:148-158, 171-186) through ee_set_inputs_embeds:
+    (1) the word rows of the tokens handed in as inputs_embeds TOGETHER with input_ids reproduce the input_ids call bit for bit (HF takes the
+    position ids from input_ids and the rows from inputs_embeds); (2) arbitrary rows WITHOUT input_ids (sequential position ids, nothing is
+    padding unless the mask says so) against oracle.forward_all, both precisions, dump-all and early exit; (3) the model mirror's forward."""
+    ee = dict(exits=["text_avg", "text_visual_concat", 1, 2], encoder_layer_strategy="ramp")
+    from .conftest import H256_KW
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
+    W = pkg.synth.make_weights(cfg, seed=51, head_gain=6.0)
+    B, T = 6, 48
+    docs = pkg.synth.make_documents(cfg, B, seed=52, text_len=T, min_words=3)
+    word = W["layoutlmv3.embeddings.word_embeddings.weight"]
+    rng = np.random.default_rng(53)
+    free = (word[rng.integers(0, cfg.vocab_size, size=(B, T))] + 0.05 * rng.standard_normal((B, T, cfg.hidden_size))).astype(np.float32)
+    for precision in ("fp32", "split"):
+        eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=precision, xprobe=False)
+        eng.load_weights(W)
+        kw = dict(attention_mask=docs["attention_mask"], bbox=docs["bbox"], pixel_values=docs["pixel_values"])
+        a = eng.forward(input_ids=docs["input_ids"], **kw, dump_all=True, want_all=True, validate=True)
+        b = eng.forward(input_ids=docs["input_ids"], inputs_embeds=word[docs["input_ids"]], **kw, dump_all=True, want_all=True, validate=True)
+        assert np.array_equal(_np(a.all_logits), _np(b.all_logits)), precision
+        c = eng.forward(input_ids=docs["input_ids"], **kw, dump_all=True, want_all=True, validate=True)      # the setter is consumed by ONE forward
+        assert np.array_equal(_np(a.all_logits), _np(c.all_logits)), precision
+        batch = dict(inputs_embeds=free, **kw)
+        ref = oracle.forward_all(cfg, W, batch, ee["exits"])
+        out = eng.forward(inputs_embeds=free, **kw, dump_all=True, want_all=True, validate=True)
+        err = float(np.abs(_np(out.all_logits) - ref["logits_store"]).max())
+        report_measured(f"inputs_embeds[{precision}]", "max|dlogit|", err)
+        assert err < LOGIT_TOL, (precision, err)
+        assert np.abs(ref["logits_store"] - oracle.forward_all(cfg, W, docs, ee["exits"])["logits_store"]).max() > 1e-3      # not vacuous
+        conf = oracle.softmax64(ref["logits_store"]).max(-1)
+        srt = np.sort(conf, axis=1)
+        thr = 0.5 * (srt[:, B // 2 - 1] + srt[:, B // 2])
+        if np.abs(conf - thr[:, None]).min() >= 1e-5:
+            ex, pred, _ = oracle.policy_scan(ref["logits_store"], thr)
+            o2 = eng.forward(inputs_embeds=free, **kw, thresholds=thr, validate=True)
+            assert np.array_equal(_np(o2.exit_layer), ex), precision
+            np.testing.assert_allclose(_np(o2.logits), pred, rtol=0, atol=LOGIT_TOL)
+        eng.close()
+    model = pkg.LayoutLMv3EEForSequenceClassification(cfg, W, max_docs=4, max_text_len=T)      # 6 documents through a 4-document engine: chunking
+    import torch
+    res = model(inputs_embeds=torch.from_numpy(free), attention_mask=torch.from_numpy(docs["attention_mask"]), bbox=torch.from_numpy(docs["bbox"]),
+                pixel_values=torch.from_numpy(docs["pixel_values"]))
+    np.testing.assert_allclose(_np(res.logits), ref["logits_store"][-1], rtol=0, atol=LOGIT_TOL)

@@ -158,3 +158,23 @@ def test_dit_oracle_matches_hf_beit_golden(pkg, oracle):
         np.testing.assert_allclose(out["hidden_cls"], g["hidden_cls"], rtol=0, atol=tol)
         np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(out["exit_crit"], g["exit_crit"], rtol=0, atol=1e-5)
+
+
+def test_inputs_embeds_restatement(pkg, oracle):
+    """HF:148-158, 171-186: word rows handed in as inputs_embeds with input_ids reproduce the input_ids result exactly (position ids come
+    from input_ids); without input_ids the default position ids are pad_token_id + 1 + t."""
+    ee = dict(exits=["text_avg", 1, 2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=3)
+    docs = pkg.synth.make_documents(cfg, 3, seed=4, text_len=24, min_words=3)
+    word = W["layoutlmv3.embeddings.word_embeddings.weight"]
+    a = oracle.forward_all(cfg, W, docs, ee["exits"])["logits_store"]
+    b = oracle.forward_all(cfg, W, dict(docs, inputs_embeds=word[docs["input_ids"]]), ee["exits"])["logits_store"]
+    assert np.array_equal(a, b)
+    no_ids = {k: v for k, v in docs.items() if k != "input_ids"}
+    T = docs["input_ids"].shape[1]
+    seq = np.broadcast_to(np.arange(cfg.pad_token_id + 1, T + cfg.pad_token_id + 1, dtype=np.int64)[None], docs["input_ids"].shape)
+    c = oracle.forward_all(cfg, W, dict(no_ids, inputs_embeds=word[docs["input_ids"]]), ee["exits"])["logits_store"]
+    d = oracle.forward_all(cfg, W, dict(docs, position_ids=seq), ee["exits"])["logits_store"]
+    assert np.array_equal(c, d)
+    assert np.abs(a - c).max() > 0          # padded documents: the pad-aware ids differ from the sequential ones
