@@ -183,6 +183,14 @@ int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask);
  * id != pad_token_id) together with the sequential position_ids of HF:148-158 (pad_token_id + 1 + t), which is what the host mirror does. */
 int ee_set_inputs_embeds(ee_handle* h, const float* embeds);
 
+/* `output_hidden_states=True` of the reference signature (EE/models/LayoutLMv3.py:386, 396-400; the encoder collects the hidden state
+ * entering every layer and the last layer's output, :164, 182-183, 284-285).  out: dev float (L+1, B, T+Pv, H) -- (L+1, B, Pv, H) for the
+ * image-only model -- filled by the NEXT ee_forward, which must carry MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS (nobody leaves, every layer
+ * runs on every document, as in the reference's forward); consumed by that call, NULL clears it.  Positions the attention mask drops hold
+ * the values the reference computes for them under MMEE_FLAG_DENSE_ROWS and zeros in the ragged layout (their rows do not exist there).
+ * In MMEE_PREC_F32_SPLIT the values are the hi + lo planes the next layer actually reads (22 significant bits). */
+int ee_set_hidden_states_out(ee_handle* h, float* out);
+
 /*
  * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]
  * (global threshold: repeat it).  exits dev int32 (N,), predictions dev double (N,K), confidence dev double (N,) or

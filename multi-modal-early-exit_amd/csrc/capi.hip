@@ -125,6 +125,7 @@ struct ee_handle {
     bool last_gate_heads = true;                  // gate strategy: were the 2-way gate heads evaluated in the last forward
     bool mask_on = false;                         // ee_set_probe_mask: the exit-layer schedule is pinned
     const float* next_inputs_embeds = nullptr;    // ee_set_inputs_embeds: read by the next ee_forward, then cleared
+    float* next_hidden_out = nullptr;             // ee_set_hidden_states_out: filled by the next ee_forward, then cleared
     uint64_t probe_mask = 0;
 };
 
@@ -750,6 +751,10 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
     if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
+    float* const hs_out = h->next_hidden_out;      // (L+1, B, T+Pv, H), ee_set_hidden_states_out
+    h->next_hidden_out = nullptr;
+    if (hs_out && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
+        return fail(h, "ee_forward: hidden states are collected in dump-all mode with whole layers only (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int H = c.hidden_size, I = c.intermediate_size, L = c.num_hidden_layers, K = c.num_labels;
     const int G = c.input_size / c.patch_size, NP = G * G, Pv = NP + 1;
@@ -1009,6 +1014,14 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (out_hidden_cls)
         launch_gather_cls((sp && !beit) ? h->Xs : h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs, out_hidden_cls, B, s,
                           (sp && !beit) ? 1.0f / mmee::kSplitScaleX : 0.f);
+    // hidden state entering layer 0 / leaving layer l (EE/models/LayoutLMv3.py:182-183, 284-285): dump-all, so stage 0's numbering holds throughout
+    auto dump_hidden = [&](int slot) {
+        if (!hs_out) return;
+        const bool spl = sp && !beit;
+        launch_rows_to_padded(spl ? reinterpret_cast<const float*>(h->Xs) : h->X, spl ? 1.0f / mmee::kSplitScaleX : 0.f, H, B, T, Pv,
+                              beit ? nullptr : h->text_dst, beit ? nullptr : h->ntext, S_doc_off(0), hs_out + (size_t)slot * B * max_len * H, s);
+    };
+    dump_hidden(0);
 
     // An exit layer: the probe pays when the rows it saves (attention, attention-out, FFN of the documents that leave) cost more than the
     // probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document), judged from the
@@ -1296,6 +1309,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (out_hidden_cls)
             launch_gather_cls(x_is_split ? h->Xs : h->X, H, x_phys, S_doc_orig(cur), &h->counts[cur].n_docs,
                               out_hidden_cls + (size_t)(l + 1) * B * H, B, s, xs_inv);
+        dump_hidden(l + 1);
         if (next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1) {
             if (x_is_split) {
                 launch_gather_cls(h->Xs, H, x_phys, nullptr, &h->counts[cur].n_docs, h->cls_f32, B, s, xs_inv);
@@ -1363,6 +1377,12 @@ int ee_set_inputs_embeds(ee_handle* h, const float* embeds) {
     if (!h) return 1;
     if (embeds && h->cfg.arch == MMEE_ARCH_BEIT) return fail(h, "ee_set_inputs_embeds: an image-only model has no text embeddings");
     h->next_inputs_embeds = embeds;
+    return 0;
+}
+
+int ee_set_hidden_states_out(ee_handle* h, float* out) {
+    if (!h) return 1;
+    h->next_hidden_out = out;
     return 0;
 }
 

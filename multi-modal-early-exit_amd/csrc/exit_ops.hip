@@ -227,6 +227,41 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict
     }
 }
 
+// Hidden states in the reference's padded layout (ee_set_hidden_states_out): position p of document d is text token p (packed row
+// text_dst[d * T + p], < 0 when the ragged layout dropped it: zeros) or visual row p - T (packed behind the document's ntext[d] text rows).
+__global__ __launch_bounds__(256) void rows_to_padded_kernel(const float* __restrict__ X, float split_inv, int H, int B, int T, int Pv,
+                                                             const int* __restrict__ text_dst, const int* __restrict__ ntext,
+                                                             const int* __restrict__ doc_off, float* __restrict__ out) {
+    const int S = T + Pv;
+    for (long r = blockIdx.x; r < (long)B * S; r += gridDim.x) {
+        const int d = (int)(r / S), p = (int)(r - (long)d * S);
+        int row;
+        if (p < T) {
+            const int t = text_dst[(size_t)d * T + p];
+            row = t < 0 ? -1 : doc_off[d] + t;
+        } else {
+            row = doc_off[d] + (text_dst ? ntext[d] : 0) + (p - T);
+        }
+        float* dst = out + (size_t)r * H;
+        if (row < 0) {
+            for (int c = threadIdx.x; c < H; c += 256) dst[c] = 0.f;
+        } else if (split_inv != 0.f) {
+            const float* src = X + (size_t)row * H;
+            for (int c = 4 * threadIdx.x; c < H; c += 1024) *reinterpret_cast<f32x4*>(dst + c) = load_split4(src, c, split_inv);
+        } else {
+            const float* src = X + (size_t)row * H;
+            for (int c = threadIdx.x; c < H; c += 256) dst[c] = src[c];
+        }
+    }
+}
+void launch_rows_to_padded(const float* X, float split_inv, int H, int B, int T, int Pv, const int* text_dst, const int* ntext, const int* doc_off,
+                           float* out, hipStream_t s) {
+    long rows = (long)B * (T + Pv);
+    int grid = rows < 4096 ? (int)rows : 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(rows_to_padded_kernel, dim3(grid), dim3(256), 0, s, X, split_inv, H, B, T, Pv, text_dst, ntext, doc_off, out);
+}
+
 void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr, float* out,
                        int max_docs, hipStream_t s, float split_inv) {
     int grid = max_docs < 2048 ? max_docs : 2048;

@@ -142,6 +142,9 @@ void launch_decide(const DecideArgs& a, hipStream_t s);
 void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,
                          const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s);
 // out[doc_orig ? doc_orig[i] : i] = CLS row of active document i; split_inv != 0: X holds split-f16 rows scaled by 1 / split_inv
+// every row of every document -> out[(d * (T + Pv) + position)][H] (ee_set_hidden_states_out); text_dst null: image-only, Pv rows per document
+void launch_rows_to_padded(const float* X, float split_inv, int H, int B, int T, int Pv, const int* text_dst, const int* ntext, const int* doc_off,
+                           float* out, hipStream_t s);
 void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr,
                        float* out, int max_docs, hipStream_t s, float split_inv = 0.f);
 void launch_policy_scan(const double* logits, int E1, int N, int K, const double* thr_dev, int* exits, double* pred,

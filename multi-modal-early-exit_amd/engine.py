@@ -34,6 +34,7 @@ class EngineOutput:
     head_logits: Optional["torch.Tensor"] = None  # (E,B,Kh) raw exit-head logits (exit_states[j][0])
     head_crit: Optional["torch.Tensor"] = None    # (E,B)    (exit_states[j][1])
     hidden_cls: Optional["torch.Tensor"] = None   # (L+1,B,H)
+    hidden_states: Optional["torch.Tensor"] = None   # (L+1,B,T+Pv,H): the state entering every layer and the last layer's output
 
 
 def _require_torch_cuda(device=None):
@@ -187,7 +188,7 @@ class EarlyExitEngine:
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
-                one_term: bool = False, inputs_embeds=None) -> EngineOutput:
+                one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False) -> EngineOutput:
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -253,6 +254,15 @@ class EarlyExitEngine:
                             device=dev) if want_hidden_cls else None
         if xprobe is None:
             xprobe = self.xprobe_default
+        hs = None
+        if want_hidden_states:
+            # output_hidden_states of the reference (EE/models/LayoutLMv3.py:182-183, 284-285): dump-all, whole layers; dense rows so that
+            # the positions the mask drops hold what the reference computes for them
+            if not dump_all:
+                raise ValueError("want_hidden_states needs dump_all=True (nobody may leave early)")
+            whole_layers, dense_rows, xprobe = True, True, False
+            S = T + (self.cfg.input_size // self.cfg.patch_size) ** 2 + 1
+            hs = torch.empty((self.cfg.num_hidden_layers + 1, B, S, self.cfg.hidden_size), dtype=torch.float32, device=dev)
         flags = ((capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0) |
                  (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0) |
                  (capi.FLAG_XPROBE if xprobe else 0) | (capi.FLAG_ONE_TERM if one_term else 0))
@@ -266,6 +276,8 @@ class EarlyExitEngine:
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             if not self.beit and emb is not None:
                 capi.check(self.lib.ee_set_inputs_embeds(self._h, p(emb)), self._h, "ee_set_inputs_embeds")
+            if hs is not None:
+                capi.check(self.lib.ee_set_hidden_states_out(self._h, p(hs)), self._h, "ee_set_hidden_states_out")
             rc = self.lib.ee_forward(self._h, p(ids), p(am), p(bb), p(px), p(tt), p(ps), B, T, thr_c, tmp_c, flags,
                                      p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
                                      p(head_logits), p(head_crit), p(hidden), stream)
@@ -273,7 +285,7 @@ class EarlyExitEngine:
         self._keepalive = (ids, am, bb, px, tt, ps, None if self.beit else emb)   # borrowed by the enqueued kernels until the stream drains
         if validate:
             self.stage_counts()                        # synchronises; raises on out-of-range inputs
-        return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden)
+        return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, hs)
 
     __call__ = forward
 

@@ -163,7 +163,8 @@ class LayoutLMv3EEForSequenceClassification:
         return EngineOutput(cat([p.logits for p in parts], 0), cat([p.exit_layer for p in parts], 0),
                             cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
                             cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
-                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1))
+                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1),
+                            cat([p.hidden_states for p in parts], 1))
 
     # ---- the reference signature -------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, bbox=None, pixel_values=None, labels=None,
@@ -176,12 +177,11 @@ class LayoutLMv3EEForSequenceClassification:
                              "(EE/utils.py:93-98); text-only / image-only calls are not built")
         if head_mask is not None:
             raise NotImplementedError("head_mask is not part of the evaluation hot path")
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / full hidden states are never materialised by the fused kernels; "
-                                      "EarlyExitEngine.forward(want_hidden_cls=True) returns the CLS row of every layer")
+        if output_attentions:
+            raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
         out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                              token_type_ids=token_type_ids, position_ids=position_ids, inputs_embeds=inputs_embeds),
-                        dump_all=True, want_all=True, want_head=True, validate=True)
+                        dump_all=True, want_all=True, want_head=True, validate=True, want_hidden_states=bool(output_hidden_states))
         return self._pack(out, labels, return_dict)
 
     def _pack(self, out: EngineOutput, labels, return_dict):
@@ -205,7 +205,9 @@ class LayoutLMv3EEForSequenceClassification:
                     exit_losses.append(F.cross_entropy(out.head_logits[j], lab))
                     exit_criteria.append(out.head_crit[j])
         exit_criteria.append(out.all_crit[E])                  # :871-872
-        res = EESequenceClassifierOutput(loss=loss, logits=logits, hidden_states=None, attentions=None,
+        # output_hidden_states (EE/models/LayoutLMv3.py:887-896 passes the encoder's tuple through): L + 1 tensors of (B, T + Pv, H)
+        hidden_states = None if out.hidden_states is None else tuple(out.hidden_states[l] for l in range(out.hidden_states.shape[0]))
+        res = EESequenceClassifierOutput(loss=loss, logits=logits, hidden_states=hidden_states, attentions=None,
                                          exit_losses=exit_losses, exit_criteria=exit_criteria, exit_states=exit_states,
                                          gated_logits=gated)
         if return_dict is False:
@@ -258,7 +260,8 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
         return EngineOutput(cat([p.logits for p in parts], 0), cat([p.exit_layer for p in parts], 0),
                             cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
                             cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
-                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1))
+                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1),
+                            cat([p.hidden_states for p in parts], 1))
 
     def early_exit(self, pixel_values=None, thresholds=None, temperatures=None, **kw) -> EngineOutput:
         if thresholds is None:

@@ -233,6 +233,7 @@ def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.
 
 def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exits: Sequence[Union[str, int]],
                 strategy: str = "ramp", criterion: str = "max_confidence", return_hidden_cls: bool = False,
+                return_hidden_states: bool = False,
                 max_layers: Optional[int] = None) -> Dict[str, np.ndarray]:
     """Full-depth forward with every exit evaluated, as the reference does at eval time
     (``LayoutLMv3EEForSequenceClassification.forward`` EE/models/LayoutLMv3.py:696-749, 871-896 ->
@@ -283,11 +284,14 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
     ext = ((1.0 - mask[:, None, None, :].astype(F32)) * np.finfo(F32).min).astype(F32)                # :622-624
     bias = attention_bias(cfg, W, fpos, fb)                                     # :170-179
     cls_rows = [x[:, 0, :].copy()]
+    all_hidden = [x.copy()] if return_hidden_states else None                   # :182-183 (the state ENTERING each layer)
     L = cfg.num_hidden_layers if max_layers is None else max_layers
     k = 0
     for l in range(L):                                                          # :181
         x = encoder_layer(cfg, W, l, x, bias, ext)
         cls_rows.append(x[:, 0, :].copy())
+        if return_hidden_states:
+            all_hidden.append(x.copy())                                         # ... and the last layer's output, :284-285
         if (l + 1) in enc_exits:                                                # :222-248
             xin = x[:, 0, :]
             ex_logits.append(exit_head(xin, W, f"{p}encoder.early_exits.{k}")); gate_inputs.append(xin.copy())
@@ -314,6 +318,8 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
     out["logits_store"] = store
     if return_hidden_cls:
         out["hidden_cls"] = np.stack(cls_rows)
+    if return_hidden_states:
+        out["hidden_states"] = np.stack(all_hidden)                             # (L+1, B, T+Pv, H)
     return out
 
 

@@ -42,7 +42,19 @@ def test_model_forward_contract(pkg, name):
     out2 = m.forward(**b)
     assert out2.loss is None and len(out2.exit_criteria) == 1 and len(out2.gated_logits) == 0
     with pytest.raises(NotImplementedError):
-        m.forward(**b, output_hidden_states=True)
+        m.forward(**b, output_attentions=True)
+    out3 = m.forward(**b, output_hidden_states=True)             # EE/models/LayoutLMv3.py:887-896: L + 1 tensors of (B, T + Pv, H)
+    mc = m.model_config
+    L, Bq = mc.num_hidden_layers, b["input_ids"].shape[0]
+    S = b["input_ids"].shape[1] + (mc.input_size // mc.patch_size) ** 2 + 1
+    assert len(out3.hidden_states) == L + 1 and all(tuple(hs.shape) == (Bq, S, mc.hidden_size) for hs in out3.hidden_states)
+    np.testing.assert_allclose(out3.logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+    if "hidden_cls" in g:                                        # rows of the composed reference's own hidden states (make_golden.py)
+        for l in range(L + 1):
+            np.testing.assert_allclose(out3.hidden_states[l][:, 0].cpu().numpy(), g["hidden_cls"][l], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out3.hidden_states[0][:, 1].cpu().numpy(), g["emb_out_row1"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out3.hidden_states[0][:, -1].cpu().numpy(), g["emb_out_lastrow"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out3.hidden_states[1][:, 1].cpu().numpy(), g["layer1_row1"], rtol=0, atol=1e-4)
 
 
 def test_harness_store_matches_golden_and_policy_roundtrip(pkg, tmp_path):

@@ -805,3 +805,45 @@ def test_inputs_embeds_vs_oracle_and_vs_input_ids(pkg, oracle):
     res = model(inputs_embeds=torch.from_numpy(free), attention_mask=torch.from_numpy(docs["attention_mask"]), bbox=torch.from_numpy(docs["bbox"]),
                 pixel_values=torch.from_numpy(docs["pixel_values"]))
     np.testing.assert_allclose(_np(res.logits), ref["logits_store"][-1], rtol=0, atol=LOGIT_TOL)
+
+
+@pytest.mark.gpu
+def test_output_hidden_states_vs_oracle(pkg, oracle):
+    """`output_hidden_states=True` of the reference signature (EE/models/LayoutLMv3.py:164, 182-183, 284-285, 887-896) through
+    ee_set_hidden_states_out: the state entering every layer and the last layer's output, every position -- the padded ones included, which the
+    reference computes like any other row (dense rows) -- against oracle.forward_all, both precisions; the ragged layout returns the same
+    rows and zeros where the mask dropped a position; the logits of the same call are unchanged."""
+    ee = dict(exits=["text_avg", 1, 2], encoder_layer_strategy="ramp")
+    from .conftest import H256_KW
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
+    W = pkg.synth.make_weights(cfg, seed=61, head_gain=6.0)
+    B, T = 5, 48
+    docs = pkg.synth.make_documents(cfg, B, seed=62, text_len=T, min_words=3)
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], return_hidden_states=True)
+    hs_ref = ref["hidden_states"]
+    Pv = (cfg.input_size // cfg.patch_size) ** 2 + 1
+    assert hs_ref.shape == (cfg.num_hidden_layers + 1, B, T + Pv, cfg.hidden_size) and (docs["attention_mask"] == 0).any()
+    for precision in ("fp32", "split"):
+        eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=precision, xprobe=False)
+        eng.load_weights(W)
+        kw = dict(input_ids=docs["input_ids"], attention_mask=docs["attention_mask"], bbox=docs["bbox"], pixel_values=docs["pixel_values"])
+        out = eng.forward(**kw, dump_all=True, want_all=True, want_hidden_states=True, validate=True)
+        err = float(np.abs(_np(out.hidden_states) - hs_ref).max())
+        report_measured(f"hidden_states[{precision}]", "max|dx|", err)
+        assert err < LOGIT_TOL, (precision, err)
+        assert float(np.abs(_np(out.all_logits) - ref["logits_store"]).max()) < LOGIT_TOL
+        plain = eng.forward(**kw, dump_all=True, want_all=True, validate=True)
+        assert float(np.abs(_np(out.all_logits) - _np(plain.all_logits)).max()) < 1e-5      # dense vs ragged rows: same results
+        with pytest.raises(ValueError):
+            eng.forward(**kw, thresholds=0.5, want_hidden_states=True)
+        # the C-ABI's ragged variant: same rows, zeros at dropped positions
+        import ctypes as C
+        import torch
+        hs = torch.full(tuple(hs_ref.shape), float("nan"), dtype=torch.float32, device=eng.device)
+        pkg.capi.check(eng.lib.ee_set_hidden_states_out(eng._h, C.c_void_p(hs.data_ptr())), eng._h, "ee_set_hidden_states_out")
+        eng.forward(**kw, dump_all=True, whole_layers=True, validate=True)
+        got = _np(hs)
+        keep = np.concatenate([docs["attention_mask"] != 0, np.ones((B, Pv), dtype=bool)], axis=1)
+        assert float(np.abs(got[:, keep] - hs_ref[:, keep]).max()) < LOGIT_TOL and not np.isnan(got).any()
+        assert np.all(got[:, ~keep] == 0)
+        eng.close()
