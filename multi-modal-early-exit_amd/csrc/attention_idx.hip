@@ -167,6 +167,12 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // XP: experiment bits kept as template switches while they are being measured (tools/attn_ab.sh, MMEE_ATTN_XP in the diagnostic library):
 //   2 = bias first: the lookups initialise the score accumulator (two adds per score instead of three, no zero init, no mid-tile wait;
 //       the index words of tile kt + 1 are fetched right behind the lookups of tile kt, before the DMA of tile kt + 2),
+//   16 = s_setprio 1 around the two MFMA phases of a tile (Q K^T with its K reads and DMA issues, P V with its V reads), 0 elsewhere: the
+//       waves of a SIMD that are in a matrix phase issue ahead of those in lookups / softmax.  PMC of round 4: the matrix pipe is busy 40 % and
+//       the VALU 48 % of the cycles, both at once only 14 %.  9.49 / 9.50 ms against 9.57 / 9.58 ms (+0.9 %, bit-identical); 32 = the reverse
+//       (priority to the VALU phases): 9.72 ms.  Shipped (kXP),
+//   (64, removed) = FOUR workgroups per CU on the two-slot ring: 128 VGPRs per lane, 136 bytes of scratch per lane -- 13.0 ms against 9.24 ms;
+//       tools/check_attn_asm.py caught the first build (the compiler spilled a Q-fragment register while its load was in flight),
 //   4 = two ring slots in use instead of three (tile kt + 1 fetched during tile kt, full wait at every tile): round 4, 256 documents x 12
 //       layers, 9.37 / 9.42 ms against 9.41 / 9.42 ms with three slots, results bit-identical -- the third slot buys nothing, but nothing
 //       that was measured needs its 16 KB either, so the path keeps three.  What the 16 KB was tried for: ONE lookup for rel_pos_x +
@@ -180,7 +186,7 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // (a held ticket starts late: the queue balances worse), six waves per workgroup (192 queries per item, two workgroups per CU, waves 4 and 5
 // issue no DMA: correct, but 13.8 ms -- a workgroup's six waves land 2, 2, 1, 1 on the four SIMDs and a second workgroup of 168-VGPR waves
 // does not fit beside it, so a CU runs six waves instead of twelve).
-constexpr int kXP = 2;
+constexpr int kXP = 2 | 16;
 // TERMS = 1 (MMEE_FLAG_ONE_TERM, a reported low-precision mode, never a parity path): both products on the hi planes only.
 template <int MODE, bool BIAS, int XP, int TERMS = 3>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
@@ -390,6 +396,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             if (MODE == 2 && (dbg & 8)) { asm volatile("" :: "v"(s[0]), "v"(s[5]), "v"(s[10]), "v"(s[15])); return; }
             unsigned vb = vs;
             asm volatile("" : "+v"(vb));
+            if (XP & 16) __builtin_amdgcn_s_setprio(1);
+            if (XP & 32) __builtin_amdgcn_s_setprio(0);
             // O^T += V^T P^T.  B operand = P^T: for k-step ks, element j of lane (query, hh) is register 8 ks + j, i.e.
             // key 16 ks + 4 hh + (j & 3) + 8 (j >> 2); the A operand takes the same key order from two transposed reads
 #pragma unroll
@@ -444,6 +452,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 }
                 __builtin_amdgcn_sched_barrier(0);        // k-step 1's fragments and split are not hoisted over k-step 0 (register pressure)
             }
+            if (XP & 16) __builtin_amdgcn_s_setprio(0);
+            if (XP & 32) __builtin_amdgcn_s_setprio(1);
         };
 
         const int n_kt = (len + KT - 1) / KT, n_full = len / KT;
@@ -535,6 +545,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             }
             // S^T = K Q^T; fragments one k-step ahead of the MFMAs; tile kt + 2's DMA pieces between them
             const unsigned kb = kbase + sb;
+            if (XP & 16) __builtin_amdgcn_s_setprio(1);      // the matrix-pipe phases issue ahead of the other waves' VALU work
+            if (XP & 32) __builtin_amdgcn_s_setprio(0);      // (measured: the other way round)
             f16x8 kh = lds_load<f16x8>(kb), kl = lds_load<f16x8>(kb ^ 128u);
 #pragma unroll
             for (int stp = 0; stp < 4; ++stp) {
@@ -555,6 +567,8 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                 kl = kln;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (XP & 16) __builtin_amdgcn_s_setprio(0);
+            if (XP & 32) __builtin_amdgcn_s_setprio(1);
             STAMP(3, tprev)
             // bias behind the Q K^T MFMAs: the index words are back when all but the pieces issued above are (they are older than those)
             if (want_idx && !BF) {
@@ -670,7 +684,10 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         switch (xp) {
             case 0: launch_idx<true, 0>(a, max_docs, num_cus, stamps, dbg, s); return;
             case 2: launch_idx<true, 2>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 22: launch_idx<true, 22>(a, max_docs, num_cus, stamps, dbg, s); return;
             case 6: launch_idx<true, 6>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 18: launch_idx<true, 18>(a, max_docs, num_cus, stamps, dbg, s); return;
+            case 34: launch_idx<true, 34>(a, max_docs, num_cus, stamps, dbg, s); return;
 
             default: break;
         }
@@ -678,7 +695,7 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
 #endif
     if (a.terms == 1 && a.pair_idx && !stamps && !dbg) { launch_idx<true, kXP, 1>(a, max_docs, num_cus, nullptr, 0, s); return; }      // MMEE_FLAG_ONE_TERM
     if (a.pair_idx) launch_idx<true, kXP>(a, max_docs, num_cus, stamps, dbg, s);
-    else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);
+    else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);      // no bias to put first
 }
 
 }  // namespace mmee
