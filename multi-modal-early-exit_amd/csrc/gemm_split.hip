@@ -132,8 +132,17 @@ __device__ __forceinline__ void split_store_tile(const GemmArgs& g, float* smem,
                 }
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                    if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
-                    else v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    if (g.resid_split_inv != 0.f) {      // split planes: hi + lo by v_fma_mix_f32, the power-of-two 1 / scale folded into the add
+                        const f32x4 r = load_split4_sum(g.resid + (size_t)rs * g.ldr, col);
+#pragma unroll
+                        for (int t = 0; t < 4; t += 2) {
+                            const f32x2 y = __builtin_elementwise_fma(f32x2{r[t], r[t + 1]}, (f32x2)(g.resid_split_inv), f32x2{v[t], v[t + 1]});
+                            v[t] = y[0];
+                            v[t + 1] = y[1];
+                        }
+                    } else {
+                        v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    }
                 }
                 if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col) = v;
             }
@@ -240,8 +249,17 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
             if (row < M) {
                 if (EPI == EPI_RESID) {
                     const int rs = g.resid_row_src ? g.resid_row_src[row] : row;
-                    if (g.resid_split_inv != 0.f) v += load_split4(g.resid + (size_t)rs * g.ldr, col, g.resid_split_inv);
-                    else v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    if (g.resid_split_inv != 0.f) {      // split planes: hi + lo by v_fma_mix_f32, the power-of-two 1 / scale folded into the add
+                        const f32x4 r = load_split4_sum(g.resid + (size_t)rs * g.ldr, col);
+#pragma unroll
+                        for (int t = 0; t < 4; t += 2) {
+                            const f32x2 y = __builtin_elementwise_fma(f32x2{r[t], r[t + 1]}, (f32x2)(g.resid_split_inv), f32x2{v[t], v[t + 1]});
+                            v[t] = y[0];
+                            v[t + 1] = y[1];
+                        }
+                    } else {
+                        v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rs * g.ldr + col);
+                    }
                 }
                 if (!OUT_SPLIT) *reinterpret_cast<f32x4*>(g.C + c_shift + (size_t)row * g.ldc + col) = v;
             }

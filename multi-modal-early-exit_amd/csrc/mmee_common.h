@@ -306,14 +306,25 @@ __device__ __forceinline__ void store_split4_quad(void* row_base, int col, const
     piece.w = take_lo ? d1 : c1;
     *reinterpret_cast<int4*>(reinterpret_cast<char*>(row_base) + (size_t)(col >> 4) * 64 + (lane & 3) * 16) = piece;
 }
-// 4 consecutive columns [col, col+4) of a split row back to f32: (hi + lo) * inv_scale — exact: hi + lo carries <= 23 significant bits
-__device__ __forceinline__ f32x4 load_split4(const void* row_base, int col, float inv_scale) {
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// 4 consecutive columns [col, col+4) of a split row back to f32.  hi + lo is exact in f32 (it carries <= 23 significant bits) and ONE
+// v_fma_mix_f32 per value computes it straight from the two f16 halves (fma(hi, 1.0, lo) with f16 sources 0 and 2) instead of two
+// conversions and an add; the plane scale is a power of two, so multiplying by its inverse -- or folding it into an fma with the value the
+// row is added to, as the GEMM's residual epilogue does -- rounds nothing: the same bits as ((float)hi + (float)lo) * inv_scale.
+__device__ __forceinline__ f32x4 load_split4_sum(const void* row_base, int col) {      // hi + lo, still carrying the plane scale
     const char* p = reinterpret_cast<const char*>(row_base) + (col >> 4) * 64 + (col & 15) * 2;
-    const f16x4 hi = *reinterpret_cast<const f16x4*>(p), lo = *reinterpret_cast<const f16x4*>(p + 32);
-    f32x4 r;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) r[t] = ((float)hi[t] + (float)lo[t]) * inv_scale;
-    return r;
+    const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(p), lo = *reinterpret_cast<const u32x2_t*>(p + 32);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %4, 1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_fma_mix_f32 %1, %4, 1.0, %6 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n\t"
+        "v_fma_mix_f32 %2, %5, 1.0, %7 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+        "v_fma_mix_f32 %3, %5, 1.0, %7 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(hi[0]), "v"(hi[1]), "v"(lo[0]), "v"(lo[1]));
+    return f32x4{r0, r1, r2, r3};
+}
+__device__ __forceinline__ f32x4 load_split4(const void* row_base, int col, float inv_scale) {
+    return load_split4_sum(row_base, col) * inv_scale;
 }
 // activation scales of the split planes (powers of two; see DESIGN.md "split precision")
 constexpr float kSplitScaleX = 16.0f;     // LayerNorm outputs (|x| up to a few tens)
