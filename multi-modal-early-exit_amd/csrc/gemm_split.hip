@@ -230,7 +230,7 @@ __device__ __forceinline__ void split_store_tile16(const GemmArgs& g, float* sme
         // nothing: a wave's LDS operations execute in order.
         asm volatile("" ::: "memory");
         const int rbase = m0 + wr * 64 + half * RB + (lane >> 4);
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < RB / 4; ++j) {
             const int rl = (lane >> 4) + 4 * j;
             const int row = rbase + 4 * j;
