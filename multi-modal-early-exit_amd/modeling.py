@@ -243,9 +243,10 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
                 return_dict=None, **kwargs) -> EESequenceClassifierOutput:
         if pixel_values is None:
             raise ValueError("pixel_values is required")
-        if head_mask is not None or output_attentions or output_hidden_states:
-            raise NotImplementedError("head_mask / attention maps / full hidden states are not part of the evaluation hot path")
-        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True, validate=True)
+        if head_mask is not None or output_attentions:
+            raise NotImplementedError("head_mask / attention maps are not part of the evaluation hot path")
+        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True, validate=True,
+                        want_hidden_states=bool(output_hidden_states))      # BeitEncoder: embedding output + every layer's output, (B, Pv, H)
         return self._pack(out, labels, return_dict)
 
     __call__ = forward

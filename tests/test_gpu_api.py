@@ -373,6 +373,12 @@ def test_dit_model_wrapper(pkg):
     assert len(out.exit_states) == 4 and len(out.exit_criteria) == 5 and out.loss is not None
     ee = m.early_exit(pixel_values=pix, thresholds=float(g["pol_thr1"]))
     assert np.array_equal(ee.exit_layer.cpu().numpy(), g["pol_exits1"])
+    out_h = m(pixel_values=pix, output_hidden_states=True)         # stock BeitEncoder semantics: embedding output + every layer, (B, Pv, H)
+    L = cfg.num_hidden_layers
+    assert len(out_h.hidden_states) == L + 1 and tuple(out_h.hidden_states[0].shape) == (pix.shape[0], (cfg.input_size // cfg.patch_size) ** 2 + 1, cfg.hidden_size)
+    for l in range(L + 1):                                          # CLS rows of the stock HF model's hidden states (make_golden.py)
+        np.testing.assert_allclose(out_h.hidden_states[l][:, 0].cpu().numpy(), g["hidden_cls"][l], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out_h.logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
 
 
 def test_checkpoint_round_trip(pkg, tmp_path):
