@@ -741,6 +741,11 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                float* out_conf, float* out_all_logits, float* out_all_crit, float* out_head_logits, float* out_head_crit,
                float* out_hidden_cls, void* stream) {
     if (!h) return 1;
+    // the one-shot side inputs belong to THIS call whether it succeeds or not (a call that fails validation must not leave them armed)
+    float* const hs_out = h->next_hidden_out;                  // (L+1, B, T+Pv, H), ee_set_hidden_states_out
+    const float* const embeds_in = h->next_inputs_embeds;      // (B, T, H), ee_set_inputs_embeds
+    h->next_hidden_out = nullptr;
+    h->next_inputs_embeds = nullptr;
     if (!h->finalized) return fail(h, "ee_forward: call ee_finalize after loading the parameters");
     const ee_config& c = h->cfg;
     const bool beit = c.arch == MMEE_ARCH_BEIT;
@@ -751,8 +756,6 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
     if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
-    float* const hs_out = h->next_hidden_out;      // (L+1, B, T+Pv, H), ee_set_hidden_states_out
-    h->next_hidden_out = nullptr;
     if (hs_out && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
         return fail(h, "ee_forward: hidden states are collected in dump-all mode with whole layers only (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -873,8 +876,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     ea.emb_pos = h->emb_pos; ea.text_dst = h->text_dst; ea.ntext = h->ntext; ea.doc_off = S_doc_off(0);
     ea.B = B; ea.T = T; ea.Pv = Pv; ea.H = H; ea.cs = c.coordinate_size; ea.ss = c.shape_size; ea.max_2d = c.max_2d_position_embeddings;
     ea.vocab = c.vocab_size; ea.type_vocab = c.type_vocab_size;
-    ea.inputs_embeds = beit ? nullptr : h->next_inputs_embeds;
-    h->next_inputs_embeds = nullptr;
+    ea.inputs_embeds = beit ? nullptr : embeds_in;
     ea.word = h->word; ea.type = h->type; ea.pos = h->pos; ea.xtab = h->xtab; ea.ytab = h->ytab; ea.htab = h->htab; ea.wtab = h->wtab;
     ea.ln1_g = h->emb_g; ea.ln1_b = h->emb_b; ea.eps1 = c.layer_norm_eps;
     ea.ln2_g = h->ln_g; ea.ln2_b = h->ln_b; ea.eps2 = c.layer_norm_eps;

@@ -846,4 +846,12 @@ def test_output_hidden_states_vs_oracle(pkg, oracle):
         keep = np.concatenate([docs["attention_mask"] != 0, np.ones((B, Pv), dtype=bool)], axis=1)
         assert float(np.abs(got[:, keep] - hs_ref[:, keep]).max()) < LOGIT_TOL and not np.isnan(got).any()
         assert np.all(got[:, ~keep] == 0)
+        # a call that fails its validation consumes the one-shot pointer too: the next forward must not write through it
+        hs.fill_(7.0)
+        pkg.capi.check(eng.lib.ee_set_hidden_states_out(eng._h, C.c_void_p(hs.data_ptr())), eng._h, "ee_set_hidden_states_out")
+        with pytest.raises(pkg.capi.MMEEError):
+            eng.forward(**kw, thresholds=0.5, whole_layers=True)          # no dump-all: refused by the library
+        eng.forward(**kw, dump_all=True, whole_layers=True, validate=True)
+        torch.cuda.synchronize()
+        assert bool((hs == 7.0).all())
         eng.close()
