@@ -194,6 +194,8 @@ class EarlyExitEngine:
         R = self.cfg.input_size
         px = self._dev(pixel_values, torch.float32, "pixel_values")
         if self.beit:                                   # image-only: (B,3,R,R) is the whole input
+            if inputs_embeds is not None:
+                raise ValueError("inputs_embeds: an image-only model has no text embeddings")
             ids = am = bb = tt = ps = None
             B, T = px.shape[0], 0
             if tuple(px.shape) != (B, self.cfg.num_channels, R, R):
