@@ -42,11 +42,13 @@ def _collective_device(t, group=None):
     return t.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
-def all_gather_results(local_rows, n_docs: int, rank: int, world: int, group=None):
+def all_gather_results(local_rows, n_docs: int, rank: int, world: int, group=None, always_collective: bool = False):
     """One all-gather of every rank's ``(n_local, C)`` rows; returns ``(n_docs, C)`` in original document order.
-    Shards may differ by one row: each rank pads to the largest shard so a single fixed-size collective suffices."""
+    Shards may differ by one row: each rank pads to the largest shard so a single fixed-size collective suffices.
+    ``always_collective``: issue the collective even at world size 1 (tests/test_gpu_api.py runs the job's exact RCCL calls on the one
+    GPU the build pool offers)."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not always_collective:
         return local_rows
     n_max = shard_size(n_docs, 0, world)
     C = local_rows.shape[1]

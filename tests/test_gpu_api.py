@@ -1,8 +1,10 @@
 """GPU: the reference-shaped surfaces (model.forward, Policy, harness) and the auxiliary kernels through the C-ABI."""
+import os
+
 import numpy as np
 import pytest
 
-from .conftest import TINY_CASES, load_golden
+from .conftest import ROOT, TINY_CASES, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -475,3 +477,38 @@ def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
     assert np.array_equal(ex[~near], ex_o[~near]) and near.sum() < 3
     np.testing.assert_array_equal(pred.numpy()[~near], pred_o[~near])
     assert abs(sum(dist.values()) - 1.0) < 1e-12 and len(np.unique(ex)) >= 2
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_job_at_world_size_one(pkg, tmp_path):
+    """The three collectives of a data-parallel job (dist.py: thresholds broadcast, max-over-ranks of the step time, the ONE all-gather of
+    [logits | exit | confidence] rows) on backend "nccl" = RCCL, with the job's dtypes and shapes, on the single GPU this pool offers: world
+    size 1 (RCCL refuses two ranks on one device -- "Duplicate GPU detected", tools/rccl_same_gpu_probe.py).  It proves RCCL accepts the
+    calls as issued (device float64 broadcast / all-reduce MAX, float32 all_gather_into_tensor of padded shards), not that they scale.
+    A child process: the process group must not outlive the test."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import importlib, sys, numpy as np
+        sys.path.insert(0, {str(ROOT)!r})
+        import torch, torch.distributed as dist
+        pkg = importlib.import_module("multi-modal-early-exit_amd")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        assert dist.get_backend() == "nccl"
+        thr = np.array([0.5, 0.25, 0.125, 2.0])
+        got = pkg.dist.broadcast_array(thr, 0, device=torch.device("cuda:0"))
+        assert np.array_equal(got, thr)
+        assert pkg.dist.max_over_ranks(0.1234, device=torch.device("cuda:0")) == 0.1234
+        rows = pkg.dist.pack_results(torch.randn(37, 16, device="cuda:0"), torch.arange(37, device="cuda:0", dtype=torch.int32) % 6,
+                                     torch.rand(37, device="cuda:0"))
+        out = pkg.dist.all_gather_results(rows, 37, 0, 1, always_collective=True)
+        torch.cuda.synchronize()
+        assert out.is_cuda and torch.equal(out, rows)
+        lg, ex, cf = pkg.dist.unpack_results(out)
+        assert torch.equal(ex.cpu(), (torch.arange(37) % 6).to(torch.int32))
+        dist.destroy_process_group()
+        print("rccl world-1 ok")
+    """)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
