@@ -178,3 +178,20 @@ def test_inputs_embeds_restatement(pkg, oracle):
     d = oracle.forward_all(cfg, W, dict(docs, position_ids=seq), ee["exits"])["logits_store"]
     assert np.array_equal(c, d)
     assert np.abs(a - c).max() > 0          # padded documents: the pad-aware ids differ from the sequential ones
+
+
+def test_hidden_states_restatement_matches_the_reference_rows(pkg, oracle):
+    """``return_hidden_states`` (EE/models/LayoutLMv3.py:164, 182-183, 284-285): the state entering every layer and the last layer's output,
+    pinned on the rows of the composed reference's own hidden states that the tiny golden holds."""
+    g = load_golden("tiny_ramp")
+    ee = TINY_CASES["tiny_ramp"]
+    cfg = pkg.ModelConfig.tiny(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    batch = {k[3:]: g[k] for k in g if k.startswith("in_") and k != "in_labels"}
+    out = oracle.forward_all(cfg, W, batch, ee["exits"], return_hidden_cls=True, return_hidden_states=True)
+    hs = out["hidden_states"]
+    assert hs.shape[0] == cfg.num_hidden_layers + 1 and np.array_equal(hs[:, :, 0], out["hidden_cls"])
+    np.testing.assert_allclose(hs[:, :, 0], g["hidden_cls"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hs[0][:, 1], g["emb_out_row1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hs[0][:, -1], g["emb_out_lastrow"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(hs[1][:, 1], g["layer1_row1"], rtol=0, atol=2e-5)
