@@ -601,6 +601,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         {
             const float l_tot = st.l + __shfl_xor(st.l, 32, 64);   // the two lane halves hold disjoint keys
             const float inv = 1.0f / (l_tot * a.qkv_scale);        // the 2^10 of the probabilities is in l as well
+            const float inv_s = inv * a.ctx_scale;
             // context row of this lane's query as split planes.  The two lane halves of a query hold neighbouring 4-column groups (hh = 0:
             // columns 8 q4 .. + 3, hh = 1: + 4 .. + 7), i.e. adjacent 8-byte pieces of the hi plane and of the lo plane.  One
             // v_permlane32_swap per dword gives the lower half both hi pieces and the upper half both lo pieces: 8 stores of 16 bytes per
@@ -610,12 +611,15 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
             for (int q4 = 0; q4 < 4; ++q4) {       // registers 4*q4 .. 4*q4+3 <-> d = 8*q4 + 4*hh + (0..3)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
+                    // o * (inv * ctx_scale): the plane scale is a power of two, so this is (o * inv) * ctx_scale bit for bit; the split is the
+                    // GEMM epilogues' 4-instruction form (same hi / lo bits as split_f16x4 below the overflow bound, overflow flagged alike)
                     f32x4 w;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[c] = (half ? st.o1[4 * q4 + c] : st.o0[4 * q4 + c]) * inv;
-                    f16x4 hi, lo;
-                    split_f16x4(w, a.ctx_scale, hi, lo, amax);
-                    const u32x2 hx = __builtin_bit_cast(u32x2, hi), lx = __builtin_bit_cast(u32x2, lo);
+                    for (int c = 0; c < 4; ++c) w[c] = (half ? st.o1[4 * q4 + c] : st.o0[4 * q4 + c]) * inv_s;
+                    unsigned h01, l01, h23, l23;
+                    split_pair(w[0], w[1], h01, l01, amax);
+                    split_pair(w[2], w[3], h23, l23, amax);
+                    const u32x2 hx = {h01, h23}, lx = {l01, l23};
                     // lanes 32-63 of the first operand swap with lanes 0-31 of the second: lower half = [own hi | partner's hi],
                     // upper half = [partner's lo | own lo]
                     const auto s0 = __builtin_amdgcn_permlane32_swap(hx[0], lx[0], false, false);
