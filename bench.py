@@ -79,6 +79,13 @@ def parse(argv=None):
                     help="comma list of 0-based layers to probe first ('' = none): pins the schedule instead of deriving it from the "
                          "warm-up (the rocprofv3 child passes get the parent's plan this way)")
     ap.add_argument("--release", type=float, default=0.2, help="fraction of arriving documents each exit releases")
+    ap.add_argument("--micro-batches", type=int, default=2,
+                    help="slices of a step's batch run on that many handles and HIP streams (MicroBatchedEngine: every kernel's tail overlaps "
+                         "the other slice's kernels; bit-identical results); 1 = one handle, one stream")
+    ap.add_argument("--no-extra-rates", action="store_true",
+                    help="skip the fixed-work rates beside the headline (full depth with MMEE_FLAG_NO_EXIT, release fractions 0.1 / 0.3)")
+    ap.add_argument("--calib-seed-offset", type=int, default=500000,
+                    help="the thresholds are calibrated on a DIFFERENT synthetic batch (seed + this) than the timed one; 0 = on the timed batch itself")
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents of the CPU baseline sample (-1 = auto, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--thresholds", default="", help="comma list of per-exit thresholds: skip the calibration pass (used for "
@@ -108,12 +115,34 @@ def _free_port():
     return p
 
 
+def fail_line(a, msg, **extra):
+    """One JSON line with "error" on stdout and a non-zero exit code: a bench that cannot run the configuration it was asked for says so in
+    the format its reader parses, instead of a bare message on stderr."""
+    print(json.dumps({"metric": "docs_per_sec", "value": None, "unit": "docs/s", "n_gpus": a.gpus, "error": msg, **extra}))
+    sys.stdout.flush()
+    sys.exit(2)
+
+
+def visible_gpus():
+    """Devices the ranks could use.  torch.cuda.device_count() does not initialise HIP on this image, so the launching parent may ask."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:  # noqa: BLE001
+        return 0
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` with no rank environment: start N ranks (one per GPU) as a CHILD
-    `python -m torch.distributed.run` and pass its output and exit code through.  This process never imports torch and
-    never touches the GPU (a process that has initialised HIP must not exec / be replaced, and the children need the
+    `python -m torch.distributed.run` and pass its output and exit code through.  This process never touches the GPU (counting
+    devices does not initialise HIP; a process that has initialised HIP must not exec / be replaced, and the children need the
     devices to themselves)."""
     import subprocess
+    if not (a.dry_launch or a.stub_engine) and os.environ.get("MMEE_DIST_BACKEND", "nccl") == "nccl":
+        n = visible_gpus()
+        if n < a.gpus:
+            fail_line(a, f"--gpus {a.gpus} needs {a.gpus} visible GPUs for its RCCL ranks, {n} visible "
+                         "(MMEE_DIST_BACKEND=gloo rehearses the flow on fewer)", visible_gpus=n)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver supports dmabuf IPC only (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
@@ -179,8 +208,12 @@ def pmc_pass(counters, child_args, timeout=300):
         env.pop(k, None)
     out = {}
     try:
-        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        if r.returncode != 0:
+            return f"{'+'.join(counters)} pass failed: rocprofv3 exit code {r.returncode}: {(r.stderr or '')[-300:].strip()}"
         f = [os.path.join(dp, x) for dp, _, fs in os.walk(d) for x in fs if x.endswith("counter_collection.csv")]
+        if not f:
+            return f"{'+'.join(counters)} pass failed: rocprofv3 wrote no counter_collection.csv"
         seen = set()
         for row in csv.DictReader(open(f[0])):
             k = out.setdefault(row["Kernel_Name"], {"_ns": []})
@@ -191,7 +224,7 @@ def pmc_pass(counters, child_args, timeout=300):
                 seen.add(did)
                 k["_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     except Exception as e:  # noqa: BLE001
-        return f"{'+'.join(counters)} pass failed: {type(e).__name__}"
+        return f"{'+'.join(counters)} pass failed: {type(e).__name__}: {e}"
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out
@@ -319,12 +352,17 @@ def main(argv=None):
     a = parse(argv)
     if a.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    if (a.gpus == 1 and "WORLD_SIZE" not in os.environ and not (a.dry_launch or a.stub_engine) and visible_gpus() < 1):
+        fail_line(a, "no GPU visible: the HIP path has no CPU fallback (the CPU oracle is test infrastructure, never the thing measured)", visible_gpus=0)
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:                       # parent of the ranks: nothing below this line runs in it
             sys.exit(launch_ranks(a))
     elif int(os.environ["WORLD_SIZE"]) != a.gpus:
-        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
-                 f"pass --gpus {os.environ['WORLD_SIZE']} (or run `python bench.py --gpus N` and let it launch the ranks)")
+        msg = (f"--gpus {a.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+               f"pass --gpus {os.environ['WORLD_SIZE']} (or run `python bench.py --gpus N` and let it launch the ranks)")
+        if int(os.environ.get("RANK", "0")) == 0:
+            fail_line(a, msg)
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -345,8 +383,11 @@ def main(argv=None):
         sync = lambda: None
     else:
         ndev = max(1, torch.cuda.device_count())
-        if backend == "nccl" and world > ndev:
-            sys.exit(f"bench.py: {world} RCCL ranks but only {ndev} GPU(s) visible (MMEE_DIST_BACKEND=gloo rehearses on fewer)")
+        if backend == "nccl" and world > torch.cuda.device_count():
+            if rank == 0:
+                fail_line(a, f"{world} RCCL ranks but only {torch.cuda.device_count()} GPU(s) visible (MMEE_DIST_BACKEND=gloo rehearses on fewer)",
+                          visible_gpus=torch.cuda.device_count())
+            sys.exit(2)
         local_dev = local % ndev if backend != "nccl" else local
         dev = torch.device(f"cuda:{local_dev}")
         torch.cuda.set_device(dev)
@@ -380,7 +421,10 @@ def main(argv=None):
         eng = _StubEngine(len(EXIT_LAYERS), cfg.num_labels)
     else:
         W = (pkg.synth.make_weights_beit if beit else pkg.synth.make_weights)(cfg, seed=a.seed, head_gain=6.0)
-        eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev)
+        if a.micro_batches > 1:
+            eng = pkg.MicroBatchedEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev, micro_batches=a.micro_batches)
+        else:
+            eng = pkg.EarlyExitEngine(cfg, max_docs=B, max_text_len=T, precision=a.precision, device=dev)
         eng.load_weights(W)
     docs = pkg.synth.make_documents(cfg, B, seed=a.seed + 1000 * rank, text_len=T if not beit else 8)
     d_px = torch.from_numpy(docs["pixel_values"]).to(dev)
@@ -391,13 +435,22 @@ def main(argv=None):
         d_am = torch.from_numpy(docs["attention_mask"]).to(dev)
         d_bb = torch.from_numpy(docs["bbox"]).to(dev)
 
-    # ---- threshold calibration on the resident batch (untimed): dump-all pass -> confidences -> per-exit thresholds ----
+    # ---- threshold calibration (untimed): dump-all pass over a DIFFERENT synthetic batch (round 5, VERDICT r04 item 2: rounds 1-4 calibrated on
+    # the timed batch itself) -> confidences -> per-exit thresholds; the timed batch then leaves through them as any unseen batch would ------
+    calib_conf = None
     if a.thresholds:
         thr = np.array([float(x) for x in a.thresholds.split(",")] + [2.0])[:len(EXIT_LAYERS) + 1]
     else:
-        out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows, temperatures=temps)
-        conf = out.all_crit.cpu().numpy().astype(np.float64)
-        thr = calibrate_thresholds(conf, a.release)
+        if a.calib_seed_offset and not stub:
+            cdocs = pkg.synth.make_documents(cfg, B, seed=a.seed + a.calib_seed_offset, text_len=T if not beit else 8)
+            c_px = torch.from_numpy(cdocs["pixel_values"]).to(dev)
+            c_in = (None, None, None) if beit else tuple(torch.from_numpy(cdocs[k]).to(dev) for k in ("input_ids", "attention_mask", "bbox"))
+            out = eng.forward(c_in[0], c_in[1], c_in[2], c_px, dump_all=True, want_all=True, dense_rows=a.dense_rows, temperatures=temps)
+            del cdocs, c_px, c_in
+        else:
+            out = eng.forward(d_ids, d_am, d_bb, d_px, dump_all=True, want_all=True, dense_rows=a.dense_rows, temperatures=temps)
+        calib_conf = out.all_crit.cpu().numpy().astype(np.float64)
+        thr = calibrate_thresholds(calib_conf, a.release)
     if world > 1:                       # every rank uses rank 0's thresholds
         thr = pkg.dist.broadcast_array(thr, 0, device=dev)
 
@@ -414,9 +467,9 @@ def main(argv=None):
     sizes = [B] * (n_mine // B) + ([n_mine % B] if n_mine % B else [])
     steps = max(len([B] * (pkg.dist.shard_size(n_job, 0, world) // B)) + (1 if pkg.dist.shard_size(n_job, 0, world) % B else 0), 1) if strong else a.steps
 
-    # ---- warm-up, then pin the exit-layer schedule: the default choice looks at whichever earlier forward has finished, which
-    # depends on timing; the plan of a forward that HAS seen a finished predecessor is frozen for everything that follows --------
-    for _ in range(a.warmup):
+    # ---- warm-up, then pin the exit-layer schedule.  The library's default (probe first at every exit layer) never changes by itself; the
+    # bench asks the cost model once (ee_suggest_probe_mask on the warm-up's stage populations) and pins its answer for everything that follows ----
+    for _ in range(max(1, a.warmup) if not (a.probe_layers is not None or a.whole_layers or a.probe_always or stub) else a.warmup):
         step()
     sync()
     if a.probe_layers is not None:
@@ -424,9 +477,7 @@ def main(argv=None):
     elif a.whole_layers or a.probe_always or stub:
         plan_layers = None
     else:
-        step(); sync()
-        step(); sync()                              # this one saw the previous one's stage populations
-        plan_layers = eng.pin_schedule()
+        plan_layers = eng.pin_schedule(None, xprobe=bool(a.xprobe))
     if world > 1 and plan_layers is not None:       # same launches on every rank: rank 0's plan
         pl = np.full(64, -1, dtype=np.int64)
         pl[:len(plan_layers)] = plan_layers
@@ -454,16 +505,21 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     sync()
+    # shader-clock stamps around the timed region (s_memtime / s_memrealtime per XCD, one-wave kernels on the launch stream): the clock the
+    # chip HELD over these steps, which differs by +-5 % between the boxes of a pool under the same load
+    stamp0 = eng.clock_stamp() if not stub else None
     t0 = time.perf_counter()
 
     # no data-path collective; the one all-gather of the per-document results closes the timed region (RCCL over xGMI)
     gathered = pkg.dist.run_sharded(run_local, n_job, rank, world)
     out = run_local.last
+    stamp1 = eng.clock_stamp() if not stub else None
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    clock_ghz, clock_per_xcd = eng.clock_ghz(stamp0, stamp1) if not stub else (None, [])
     layer_of_exit = np.array(list(EXIT_LAYERS) + [cfg.num_hidden_layers])
     # work and stage populations of the HEADLINE schedule's last step (rounds 1-3 read them behind the K | V-probe A/B below, whose forward
     # projects Q | K | V for every row: executed_tflops was 3.5 % high)
@@ -482,7 +538,8 @@ def main(argv=None):
         kv_dlogit = float((o_kv.logits - out.logits).abs().max())
     # per-rank view: compute time before the all-gather, documents, mean exit layer (exit depth varies per document, so an uneven
     # deal is the one thing that can bend the scaling curve)
-    my_ex = gathered[rank::world, cfg.num_labels].cpu().numpy().astype(np.int64) if world > 1 else None
+    g_logits, g_exit, g_conf = pkg.dist.unpack_results(gathered)      # (f32 logits, i32 exit_layer, f32 confidence): the north-star contract
+    my_ex = g_exit[rank::world].cpu().numpy().astype(np.int64) if world > 1 else None
     if world > 1:
         dt = pkg.dist.max_over_ranks(dt, device=dev)
         mine = np.array([t_local[0] * 1e3, float(n_mine), float(layer_of_exit[my_ex].mean()) if len(my_ex) else 0.0])
@@ -491,7 +548,7 @@ def main(argv=None):
         per_rank = None
 
     n_docs = gathered.shape[0]
-    exits = gathered[:, cfg.num_labels].cpu().numpy().astype(np.int64)
+    exits = g_exit.cpu().numpy().astype(np.int64)
 
     # Reported beside the headline, NEVER as `value` (SURVEY 8d config 2 / BASELINE.md section 4: "bf16 throughput mode reports its measured
     # deviation separately"): the same steps with ONE f16 MFMA term per MAC in the layer GEMMs and the attention (MMEE_FLAG_ONE_TERM)
@@ -513,6 +570,56 @@ def main(argv=None):
                    "what": "MMEE_FLAG_ONE_TERM: hi planes only (plain f16 operands, f32 accumulate) in the four layer GEMMs and the attention; "
                            "CLS probes and exit heads keep three terms; same thresholds as the headline run.  Outside the 1e-4 parity bar by "
                            "construction: a measured deviation, not a result"}
+
+    # ---- fixed-work rates beside the headline (N = 1): the exit mix is a free parameter that moves docs/s far more than
+    # any kernel change, and the boxes of a pool hold different clocks.  (i) the same batch at FULL depth (MMEE_FLAG_NO_EXIT: every layer,
+    # every exit head, nobody leaves -- fixed work, mix-independent); (ii) the same batch under thresholds calibrated for release fractions
+    # 0.1 and 0.3 (same calibration batch); each with its own clock stamps, so that docs/s per GHz can be compared between leases ----------
+    extra_rates = None
+    if world == 1 and not stub and not strong and not a.thresholds and not a.no_extra_rates and calib_conf is not None:
+        ceiling = PEAK_F32_MFMA_TFLOPS if eng.precision in ("fp32", "f32") else PEAK_F16_MFMA_TFLOPS / SPLIT_TERMS
+
+        def timed(fn, nsteps):
+            fn(); sync()
+            sa = eng.clock_stamp()
+            t1 = time.perf_counter()
+            o_ = None
+            for _ in range(nsteps):
+                o_ = fn()
+            sb = eng.clock_stamp()
+            sync()
+            d_ = time.perf_counter() - t1
+            return nsteps * B / d_, eng.clock_ghz(sa, sb)[0], o_, d_ / nsteps
+
+        k2 = max(2, min(a.steps, 4))
+        fwd = lambda **kw: eng.forward(d_ids, d_am, d_bb, d_px, dense_rows=a.dense_rows, temperatures=temps, **kw)
+        r_, g_, _, spt = timed(lambda: fwd(dump_all=True), k2)
+        fl_ne = eng.flops()
+        extra_rates = {"steps_each": k2,
+                       "no_exit": {"docs_per_sec": r_, "clock_ghz": g_, "docs_per_sec_per_ghz": (r_ / g_) if g_ else None,
+                                   "executed_tflop_per_step": fl_ne["total"] / 1e12, "step_frac_of_ceiling": fl_ne["total"] / spt / 1e12 / ceiling,
+                                   "what": "MMEE_FLAG_NO_EXIT: all layers and every exit head for every document of the same batch (whole layers; "
+                                           "the reference's own evaluation mode, EE/utils.py:63-71): fixed work, independent of thresholds"}}
+        for rel in (0.1, 0.3):
+            thr_r = calibrate_thresholds(calib_conf, rel)
+            f_ = lambda: fwd(thresholds=thr_r, whole_layers=a.whole_layers, probe_always=a.probe_always, xprobe=bool(a.xprobe))
+            if plan_layers is not None:      # this mix's own plan, priced by the same cost model from one forward under the default schedule
+                eng.pin_schedule(False)
+                f_(); sync()
+                pl_r = eng.pin_schedule(None, xprobe=bool(a.xprobe))
+            else:
+                pl_r = None
+            r_, g_, o_, spt = timed(f_, k2)
+            fl_r = eng.flops()
+            ex_r = o_.exit_layer.cpu().numpy().astype(np.int64)
+            extra_rates[f"release_{rel}"] = {"docs_per_sec": r_, "clock_ghz": g_, "docs_per_sec_per_ghz": (r_ / g_) if g_ else None,
+                                             "mean_exit_layer": float(layer_of_exit[ex_r].mean()), "probe_layers": pl_r,
+                                             "step_frac_of_ceiling": fl_r["total"] / spt / 1e12 / ceiling,
+                                             "thresholds": [round(float(t), 6) for t in thr_r[:-1]]}
+        if plan_layers is not None:
+            eng.pin_schedule(plan_layers)
+        else:
+            eng.pin_schedule(False)
 
     line = {
         "metric": "docs_per_sec", "value": n_docs / dt, "unit": "docs/s", "n_gpus": world,
@@ -537,11 +644,19 @@ def main(argv=None):
                                    f"probe first at layers {plan_layers} (0-based; plan of a warm-up forward, pinned)") +
                                   (", CLS context in X space (xprobe)" if a.xprobe else ""),
                    "parallelism": f"dp{world}", "thresholds": [round(float(t), 6) for t in thr[:-1]],
-                   "release_fraction_per_exit": a.release},
+                   "release_fraction_per_exit": a.release,
+                   "thresholds_calibrated_on": ("--thresholds" if a.thresholds else "the timed batch itself" if not a.calib_seed_offset or stub else
+                                                f"a different synthetic batch (seed {a.seed + a.calib_seed_offset}; the timed batch is seed {a.seed})"),
+                   "micro_batches": getattr(eng, "n", 1)},
         **({"kv_probe": {"docs_per_sec": kv_probe_rate, "what": "--no-xprobe: probe-first layers read the layer's K | V rows (bit-identical "
                          "to whole layers) instead of the X-space CLS context", "exit_index_equal_to_headline_run": kv_same_exits,
                          "max_abs_dlogit_vs_headline_run": kv_dlogit}} if kv_probe_rate is not None else {}),
         **({"lowprec": lowprec} if lowprec is not None else {}),
+        # the shader clock held over the timed region (rank 0; s_memtime / s_memrealtime stamps, mean over the XCDs) and the rate per GHz:
+        # two leases of the pool that hold different clocks should agree on the latter
+        "clock_ghz_timed_region": clock_ghz, "clock_ghz_per_xcd": [round(x, 4) for x in clock_per_xcd],
+        "docs_per_sec_per_ghz": (n_docs / dt / clock_ghz) if clock_ghz else None,
+        **({"docs_per_sec_no_exit": extra_rates["no_exit"]["docs_per_sec"], "fixed_work_rates": extra_rates} if extra_rates else {}),
         "mean_exit_layer": float(layer_of_exit[exits].mean()), "mean_exit_index": float(exits.mean()),
         "exit_distribution": {str(int(layer_of_exit[e])): float((exits == e).mean()) for e in range(len(layer_of_exit))},
         "stage_docs_last_step_rank0": counts["docs"], "executed_tflop_per_step_rank0": fl["total"] / 1e12,
@@ -562,7 +677,7 @@ def main(argv=None):
     if rank == 0 and not a.no_profile and not stub:
         # ---- rooflines, live: HIP events around every launch of one more (untimed) step of the SAME pinned schedule --------------
         eng.profile(True)
-        step()
+        step(**({"serial": True} if getattr(eng, "n", 1) > 1 else {}))      # micro-batches one after the other: overlapping launches would be timed twice
         prof = eng.profile_read()
         eng.profile(False)
         c = eng.stage_counts()
@@ -633,8 +748,8 @@ def main(argv=None):
                                 "roles": hb}
 
         if world == 1 and not a.no_traffic:
-            child = ["--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic", "--stream-docs", "0",
-                     "--batch", str(B), "--precision", eng.precision if eng.precision != "split" else "split", "--workload", a.workload,
+            child = ["--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic", "--stream-docs", "0", "--no-extra-rates",
+                     "--micro-batches", str(a.micro_batches), "--batch", str(B), "--precision", eng.precision if eng.precision != "split" else "split", "--workload", a.workload,
                      "--release", str(a.release), "--thresholds", ",".join(repr(float(t)) for t in thr[:-1]),
                      "--probe-layers", ",".join(str(x) for x in (plan_layers or []))]
             if a.dense_rows:
@@ -681,6 +796,9 @@ def main(argv=None):
                     hb["layernorm"]["traffic_bytes"] = (2.0 * fl_["FETCH_SIZE"][0] + wl_["WRITE_SIZE"][0]) * 1024.0
             else:
                 detail = {"failed": [v for v in passes.values() if isinstance(v, str)]}
+            if line["roofline"].get("traffic") is None:
+                # a failed counter pass is part of the line, not a silently missing field
+                line["roofline"]["traffic_error"] = "; ".join(v for v in passes.values() if isinstance(v, str)) or "counter rows for the FFN-up kernel not found in the pmc output"
             line["roofline"]["traffic_detail"] = detail
 
     if rank == 0 and world == 1 and a.stream_docs > 0 and not beit and not stub and not strong:
@@ -700,7 +818,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         sdt = time.perf_counter() - t1
         eng.check()                                  # every forward of the stream has been looked at (errors are kept per forward)
-        sex = srows[:, cfg.num_labels].cpu().numpy().astype(np.int64)
+        sex = pkg.dist.unpack_results(srows)[1].cpu().numpy().astype(np.int64)
         line["feed_inclusive_docs_per_sec"] = len(stream) / sdt
         line["feed_inclusive"] = {"docs": len(stream), "distinct_documents": True, "seconds": sdt,
                                   "h2d_bytes_per_doc": feeder.bytes_h2d / max(1, len(stream)),

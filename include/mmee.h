@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MMEE_ABI_VERSION 2
+#define MMEE_ABI_VERSION 3
 #define MMEE_MAX_ENCODER_EXITS 64
 
 /* embedding-level exits, in the order the reference evaluates them (EE/models/LayoutLMv3.py:465-605) */
@@ -66,10 +66,10 @@ enum {
                                   (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
     MMEE_FLAG_WHOLE_LAYERS = 4,/* run every encoder layer whole before its exit decision (what the reference does,
                                   EE/models/LayoutLMv3.py:757-768), never "probe first" (ee_last_layer_plan)          */
-    MMEE_FLAG_PROBE_ALWAYS = 8,/* probe first at every layer that ends in a decision.  With neither flag the choice is made per
-                                  exit layer from the stage populations of the handle's most recent finished forward (a probe
-                                  pays when enough rows leave; the last layer is always probed).  All three give identical
-                                  results bit for bit: the flags only pin the schedule, for A/B runs and tests          */
+    MMEE_FLAG_PROBE_ALWAYS = 8,/* probe first at every layer that ends in a decision, whatever ee_set_probe_mask pinned.  With neither flag
+                                  and no pinned mask this is also the DEFAULT (round 5): the schedule is a function of the call, never of
+                                  timing or of earlier forwards.  Whole layers, probe-first and any pinned mix give identical results bit for
+                                  bit without MMEE_FLAG_XPROBE; the flags only pin the schedule, for A/B runs and tests          */
     MMEE_FLAG_ONE_TERM = 32,   /* REPORTED low-precision mode, never a parity path (SURVEY 8d config 2 "bf16 throughput mode reports its measured
                                   deviation separately"): the layer GEMMs and the attention of an MMEE_PREC_F32_SPLIT LayoutLMv3 handle run ONE f16
                                   MFMA term per MAC (hi planes only, f32 accumulate) instead of three; CLS probes and exit heads keep three.  Logits
@@ -168,13 +168,28 @@ int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* st
 int ee_last_layer_plan(ee_handle* h, int32_t* rows_qkv, int32_t* rows_main, int32_t* docs_probe, int32_t cap, double* probe_flops,
                        void* stream);
 
-/* Pin the exit-layer schedule.  By default a layer that ends in a decision is probed first only where that pays, judged from the stage
- * populations of the handle's most recent FINISHED forward -- which forward that is depends on timing, so two runs of the same inputs
- * may schedule differently (same results bit for bit, different launch sequence and time).  enabled != 0: bit l of `mask` says whether
- * encoder layer l (0-based) is probed first; layers without an exit ignore their bit, the last layer is always probed, and
- * MMEE_FLAG_WHOLE_LAYERS / MMEE_FLAG_PROBE_ALWAYS still override.  enabled == 0: back to the default.  Benchmarks and profiles pin the
- * plan of a warm-up forward (ee_last_layer_plan: docs_probe[l] > 0) so that every measured step runs the same launches. */
+/* The exit criterion of every LATER ee_forward (MMEE_CRIT_*; ee_config.criterion is its initial value).  The reference's evaluation driver
+ * overrides `model.config.exit_config["inference_strategy"]` after the model has been built (EE/utils.py:62-78); the Python mirror forwards that
+ * write here so that those lines run unchanged. */
+int ee_set_criterion(ee_handle* h, int32_t criterion);
+
+/* Pin the exit-layer schedule.  DEFAULT (enabled == 0): every layer that ends in a decision is probed first.  Rounds 2-4 chose per layer
+ * from the stage populations of "the handle's most recent FINISHED forward" -- a timing-dependent host decision, and under MMEE_FLAG_XPROBE
+ * (whose probe is a re-association) the same inputs could return different low bits from run to run.  Round 5: the library never picks a
+ * schedule by itself; the same call always issues the same launches and returns the same bits (the reference's policy is deterministic,
+ * EE/policy.py:28-45).  enabled != 0: bit l of `mask` says whether encoder layer l (0-based) is probed first; layers without an exit ignore
+ * their bit, the last layer is always probed, and MMEE_FLAG_WHOLE_LAYERS / MMEE_FLAG_PROBE_ALWAYS still override.  The mask stays until it is
+ * changed: it is part of the handle's configuration, like the thresholds are part of the call. */
 int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask);
+/* The priced alternative to "probe everywhere": which exit layers are worth probing first, judged by a cost model from the
+ * stage populations of the LAST ee_forward on this handle, which must have been a thresholded one (synchronises).  `flags`: the flags the
+ * caller is going to run with (MMEE_FLAG_XPROBE changes the probe's price).  A pure function of those populations: the caller decides whether
+ * to pin the result with ee_set_probe_mask (bench.py and EarlyExitEngine.pin_schedule() do, once, after a warm-up forward). */
+int ee_suggest_probe_mask(ee_handle* h, uint32_t flags, uint64_t* mask_out, void* stream);
+/* Shader-clock stamps: out16_dev (dev uint64[16]) receives, per XCD x, out[2x] = s_memtime (shader clocks) and out[2x + 1] = s_memrealtime
+ * (100 MHz) as seen by a one-wave kernel enqueued on `stream`.  Two stamps around a region give the clock the chip HELD over it:
+ * d(out[2x]) / d(out[2x + 1]) x 0.1 GHz (bench.py `docs_per_sec_per_ghz`: the boxes of a pool hold different clocks under the same load). */
+int ee_clock_stamp(uint64_t* out16_dev, void* stream);
 
 /* `inputs_embeds` of the reference signature (EE/models/LayoutLMv3.py:383, 414-417 -> LayoutLMv3TextEmbeddings.forward, HF:185-186:
  * "if inputs_embeds is None: inputs_embeds = self.word_embeddings(input_ids)").  embeds: dev float (B,T,H) of the NEXT ee_forward call, read

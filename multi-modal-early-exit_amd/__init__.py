@@ -8,6 +8,7 @@ from .config import (EarlyExitHead, EarlyExitInference, EarlyExitStrategy, ExitC
                      POSSIBLE_EXITS, parse_exits)
 from . import capi  # noqa: F401,E402
 from .engine import EarlyExitEngine, EngineOutput, load_checkpoint_tensors, save_checkpoint  # noqa: F401,E402
+from .microbatch import MicroBatchedEngine  # noqa: F401,E402
 from .modeling import (DiTEEForImageClassification, EEModelOutput, EESequenceClassifierOutput,  # noqa: F401,E402
                        LayoutLMv3EEForSequenceClassification, load_local_processor)
 from .policy import Policy, policy_scan_device  # noqa: F401,E402

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_ENCODER_EXITS = 64
 EXIT_KIND = {"vision_avg": 0, "text_avg": 1, "text_visual_concat": 2}
 FLAG_DENSE_ROWS = 1
@@ -68,6 +68,9 @@ SYMBOLS = {
     "ee_last_flops": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "ee_last_layer_plan": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(C.c_double), _vp]),
     "ee_set_probe_mask": (C.c_int, [_vp, _i32, C.c_uint64]),
+    "ee_set_criterion": (C.c_int, [_vp, _i32]),
+    "ee_suggest_probe_mask": (C.c_int, [_vp, _u32, C.POINTER(C.c_uint64), _vp]),
+    "ee_clock_stamp": (C.c_int, [_vp, _vp]),
     "ee_set_inputs_embeds": (C.c_int, [_vp, _vp]),
     "ee_set_hidden_states_out": (C.c_int, [_vp, _vp]),
     "ee_policy_scan": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(C.c_double), _vp, _vp, _vp, _vp, _vp]),

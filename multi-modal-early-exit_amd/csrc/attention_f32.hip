@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void attention_f32_kernel(const AttnArgs a)
 
 void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s) {
     const size_t lds = attention_f32_lds_bytes(a);
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_f32_kernel), 160 * 1024);
+    (void)ensure_dynamic_lds<&attention_f32_kernel>("attention_f32_kernel", 160 * 1024);
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
     int grid = 3 * num_cus;

@@ -649,10 +649,10 @@ bool attention_idx_supports(const AttnArgs& a) {
 
 template <bool BIAS, int XP, int TERMS = 3>
 static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<0, BIAS, XP, TERMS>), LDS_BYTES);
+    (void)ensure_dynamic_lds<&attention_idx_kernel<0, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
 #ifdef MMEE_DIAG
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<1, BIAS, XP, TERMS>), LDS_BYTES);
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_idx_kernel<2, BIAS, XP, TERMS>), LDS_BYTES);
+    (void)ensure_dynamic_lds<&attention_idx_kernel<1, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
+    (void)ensure_dynamic_lds<&attention_idx_kernel<2, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
 #endif
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;

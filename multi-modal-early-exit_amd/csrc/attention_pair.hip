@@ -485,10 +485,10 @@ bool attention_pair_supports(const AttnArgs& a, int max_rel_pos, int max_rel_2d_
 template <int HP>
 static void launch_pair_hp(const AttnArgs& a, int max_docs, int num_cus, int r1, int r2, int any_masked, unsigned long long* stamps, int dbg,
                            hipStream_t s) {
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 0>), Lds<HP>::BYTES);
+    (void)ensure_dynamic_lds<&attention_pair_kernel<HP, 0>>("attention_pair_kernel", Lds<HP>::BYTES);
 #ifdef MMEE_DIAG
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 1>), Lds<HP>::BYTES);
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_pair_kernel<HP, 2>), Lds<HP>::BYTES);
+    (void)ensure_dynamic_lds<&attention_pair_kernel<HP, 1>>("attention_pair_kernel", Lds<HP>::BYTES);
+    (void)ensure_dynamic_lds<&attention_pair_kernel<HP, 2>>("attention_pair_kernel", Lds<HP>::BYTES);
 #endif
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * (a.heads / HP) * qtiles;

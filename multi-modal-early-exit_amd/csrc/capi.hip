@@ -110,11 +110,6 @@ struct ee_handle {
     ErrSlot errs[kErrSlots];
     int* err_host = nullptr;                      // [kErrSlots] pinned
     unsigned err_seq = 0;                         // forwards enqueued so far
-    // stage counts of recent forwards, copied to pinned host memory behind each forward (a ring: the caller may enqueue several
-    // forwards before any has finished).  They only steer a scheduling choice (probe-first or whole exit layers), never a result.
-    struct HistSlot { hipEvent_t done = nullptr; StageCounts* counts = nullptr; int B = 0; bool used = false; };
-    HistSlot hist[4];
-    unsigned fwd_seq = 0;
     // bookkeeping of the last forward
     int last_B = 0, last_T = 0, last_stages = 0;
     std::vector<int> layer_stage;                 // stage whose rows the layer's attention / attention-out / FFN ran on; -1: none (probe only)
@@ -571,10 +566,6 @@ int ee_destroy(ee_handle* h) {
     if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
     if (h->err_host) (void)hipHostFree(h->err_host);
     for (auto& es : h->errs) if (es.done) (void)hipEventDestroy(es.done);
-    for (auto& hs : h->hist) {
-        if (hs.counts) (void)hipHostFree(hs.counts);
-        if (hs.done) (void)hipEventDestroy(hs.done);
-    }
     for (void* q : h->allocs) (void)hipFree(q);
     delete h;
     return 0;
@@ -756,6 +747,8 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
     if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
+    if ((flags & MMEE_FLAG_ONE_TERM) && (beit || !h->split))
+        return fail(h, "ee_forward: MMEE_FLAG_ONE_TERM exists for MMEE_PREC_F32_SPLIT LayoutLMv3 handles only");
     if (hs_out && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
         return fail(h, "ee_forward: hidden states are collected in dump-all mode with whole layers only (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -790,13 +783,6 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         if (e) return report_errors(h, e, "a PREVIOUS forward on this handle");
     }
     if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
-    // the most recent thresholded forward that has finished: its stage populations predict this one's (steady streams repeat)
-    const StageCounts* prev = nullptr;
-    int prev_B = 0;
-    for (unsigned k = 1; k <= 4 && !prev; ++k) {
-        const ee_handle::HistSlot& hs = h->hist[(h->fwd_seq - k) & 3];
-        if (hs.used && hipEventQuery(hs.done) == hipSuccess) { prev = hs.counts; prev_B = hs.B; }
-    }
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
     h->next_queue_head = 0;
@@ -907,7 +893,9 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     // split mode, LayoutLMv3: the embedding kernels wrote the rows as split planes (Xs); later layers get theirs from the LayerNorm kernel
     // MMEE_FLAG_ONE_TERM: the layer GEMMs and the attention of a split-precision LayoutLMv3 handle on ONE f16 MFMA term (hi planes only): the
     // "bf16 throughput mode" of SURVEY 8d as a REPORTED deviation (bench.py `lowprec`), never a parity path; probes and heads keep three terms
-    const bool one_term = (flags & MMEE_FLAG_ONE_TERM) && sp;
+    // (LayoutLMv3 handles only, as include/mmee.h says: on a BEiT / DiT handle the flag is refused above -- ADVICE r04: it used to give an
+    // undocumented mix of one-term residual GEMMs and three-term everything else)
+    const bool one_term = (flags & MMEE_FLAG_ONE_TERM) && sp && !beit;
     auto run_gemm = [&](const GemmArgs& g_in, int epi) {
         GemmArgs g = g_in;
         g.terms = one_term ? 1 : 3;
@@ -1025,21 +1013,9 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     };
     dump_hidden(0);
 
-    // An exit layer: the probe pays when the rows it saves (attention, attention-out, FFN of the documents that leave) cost more than the
-    // probe itself (a pass over every K | V row for the CLS queries + three latency-bound GEMMs on one row per document), judged from the
-    // stage populations of the last finished forward; no history: probe.  Rates as measured on MI355X; both orders
-    // give the same bits, only the time differs.
-    // xs: the probe would run in X space (xprobe.hip): it streams the 4 H bytes of a LayerNorm row instead of 8 H of K | V, costs three more
-    // small launches, and a leaving row also skips its Q | K | V projection
-    auto probe_pays = [&](bool xs = false) -> bool {
-        if (!prev || prev_B <= 0 || prev[cur].n_rows <= 0) return true;
-        const double scale = (double)B / prev_B;
-        const double rows = prev[cur].n_rows * scale, leave = (prev[cur].n_rows - prev[cur + 1].n_rows) * scale;
-        const double len = (double)prev[cur].sum_len_sq / prev[cur].n_rows;                   // mean keys per query
-        const double t_row = 2.0 * ((double)H * H + 2.0 * (double)H * I + (xs ? 3.0 * (double)H * H : 0.0)) / 380e12 + 4.0 * len * H / 200e12;
-        const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + (xs ? 180e-6 + rows * 4.0 * H / 4.5e12 : 100e-6 + rows * 8.0 * H / 3.6e12);
-        return leave * t_row > 1.1 * cost;
-    };
+    // Which exit layers are probed first is part of the CALL, never of timing or history (round 5): every layer that ends
+    // in a decision unless ee_set_probe_mask pinned a subset (ee_suggest_probe_mask prices one from a finished forward's stage populations;
+    // the caller decides whether to pin it).  The same inputs therefore always run the same launch sequence and return the same bits.
     int next_enc = 0;
     for (int l = 0; l < L; ++l) {
         const LayerW& w = h->layers[l];
@@ -1123,7 +1099,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             const bool exit_here = next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == l + 1;
             // the mean-pooled final classifier reads every row of the last layer: only exit layers before it can be probed
             bool probe = probe_on && sp && !no_exit && exit_here && l != L - 1;
-            if (probe && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays();
+            if (probe && !(flags & MMEE_FLAG_PROBE_ALWAYS) && h->mask_on) probe = ((h->probe_mask >> l) & 1u) != 0;
             beit_qkv();
             if (probe) {
                 beit_probe();
@@ -1263,7 +1239,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             chk.H = H; chk.heads = c.num_attention_heads; chk.bins1 = c.rel_pos_bins; chk.bins2 = c.rel_2d_pos_bins; chk.pair_idx = h->pair_idx;
             xspace = mmee::xprobe_supports(chk, max_len);
         }
-        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS)) probe = h->mask_on ? ((h->probe_mask >> l) & 1u) != 0 : probe_pays(xspace);
+        if (probe && !last && !(flags & MMEE_FLAG_PROBE_ALWAYS) && h->mask_on) probe = ((h->probe_mask >> l) & 1u) != 0;
         if (probe && xspace) {
             // decide first, project afterwards: no Q | K | V exists yet
             layer_probe(true);
@@ -1342,21 +1318,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         h->errs[k].pending = true;
         ++h->err_seq;
     }
-    {
-        ee_handle::HistSlot& hs = h->hist[h->fwd_seq & 3];
-        hs.used = false;
-        if (!no_exit) {                  // a dump keeps every document to the end: it says nothing about the exits
-            if (!hs.done) HIP_OK(h, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
-            if (!hs.counts) HIP_OK(h, hipHostMalloc((void**)&hs.counts, sizeof(StageCounts) * (size_t)(E + 2), hipHostMallocDefault));
-            HIP_OK(h, hipMemcpyAsync(hs.counts, h->counts, sizeof(StageCounts) * (size_t)(E + 2), hipMemcpyDeviceToHost, s));
-            HIP_OK(h, hipEventRecord(hs.done, s));
-            hs.B = B;
-            hs.used = true;
-        }
-        ++h->fwd_seq;
-    }
     HIP_OK(h, hipEventRecord(h->fwd_done, s));
     h->last_stream = s; h->has_fwd = true;
+    {
+        char lds_msg[192];
+        if (mmee::take_lds_error(lds_msg, sizeof(lds_msg))) { (void)hipGetLastError(); return fail(h, "ee_forward: %s", lds_msg); }
+    }
     HIP_OK(h, hipGetLastError());
     return 0;
 }
@@ -1388,10 +1355,79 @@ int ee_set_hidden_states_out(ee_handle* h, float* out) {
     return 0;
 }
 
+int ee_set_criterion(ee_handle* h, int32_t criterion) {
+    if (!h) return 1;
+    if (criterion != MMEE_CRIT_MAX_CONFIDENCE && criterion != MMEE_CRIT_ENTROPY) return fail(h, "ee_set_criterion: unknown criterion %d", criterion);
+    h->cfg.criterion = criterion;      // read by the decide kernel's arguments of every later ee_forward
+    return 0;
+}
+
 int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask) {
     if (!h) return 1;
     h->mask_on = enabled != 0;
     h->probe_mask = mask;
+    return 0;
+}
+
+// The cost model that used to pick the schedule inside ee_forward from "whichever earlier forward had finished" (rounds 2-4), as an explicit,
+// deterministic query: which exit layers are worth probing first, judged from the stage populations of the LAST forward on this handle.  A
+// probe pays when the rows it saves (attention, attention-out, FFN -- and under MMEE_FLAG_XPROBE the Q | K | V projection -- of the documents
+// that leave) cost more than the probe itself (a pass over every K | V row, or every LayerNorm row in X space, for the CLS queries + three
+// latency-bound GEMMs on one row per document).  Rates as measured on MI355X.
+int ee_suggest_probe_mask(ee_handle* h, uint32_t flags, uint64_t* mask_out, void* stream) {
+    if (!h || !mask_out) return fail(h, "ee_suggest_probe_mask: null argument");
+    if (!h->last_stages) return fail(h, "ee_suggest_probe_mask: no forward has run");
+    if (h->last_flags & MMEE_FLAG_NO_EXIT) return fail(h, "ee_suggest_probe_mask: the last forward was a dump (nobody left): run a thresholded forward first");
+    HIP_OK(h, hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    std::vector<StageCounts> sc(h->last_stages + 1);
+    HIP_OK(h, hipMemcpy(sc.data(), h->counts, sizeof(StageCounts) * (h->last_stages + 1), hipMemcpyDeviceToHost));
+    const ee_config& c = h->cfg;
+    const bool beit = c.arch == MMEE_ARCH_BEIT;
+    const double H = c.hidden_size, I = c.intermediate_size;
+    const int L = c.num_hidden_layers;
+    uint64_t mask = 0;
+    bool xs = false;
+    if (h->split && !beit && (flags & MMEE_FLAG_XPROBE) && h->Qc && h->pair_idx && c.rel_pos_bins <= 64 && c.rel_2d_pos_bins <= 64) {
+        mmee::XProbeArgs chk{};
+        chk.H = c.hidden_size; chk.heads = c.num_attention_heads; chk.bins1 = c.rel_pos_bins; chk.bins2 = c.rel_2d_pos_bins; chk.pair_idx = h->pair_idx;
+        const int G = c.input_size / c.patch_size;
+        xs = mmee::xprobe_supports(chk, h->last_T + G * G + 1);
+    }
+    for (int k = 0; k < c.n_encoder_exits && h->split; ++k) {
+        const int l = c.encoder_exit_layers[k] - 1;
+        if (l == L - 1) continue;                     // the last layer: always the probe alone (LayoutLMv3) / always whole (BEiT mean pooling)
+        const int st = c.n_embedding_exits + k;      // stage whose documents reach this decision
+        if (st + 1 > h->last_stages) break;
+        const double rows = sc[st].n_rows, leave = (double)sc[st].n_rows - (double)sc[st + 1].n_rows;
+        if (rows <= 0) { mask |= 1ull << l; continue; }
+        const double len = (double)sc[st].sum_len_sq / rows;      // mean keys per query
+        const double t_row = 2.0 * (H * H + 2.0 * H * I + (xs ? 3.0 * H * H : 0.0)) / 380e12 + 4.0 * len * H / 200e12;
+        const double cost = ((2.0 * H + I) / 32.0) * 0.9e-6 + (xs ? 180e-6 + rows * 4.0 * H / 4.5e12 : 100e-6 + rows * 8.0 * H / 3.6e12);
+        if (leave * t_row > 1.1 * cost) mask |= 1ull << l;
+    }
+    *mask_out = mask;
+    return 0;
+}
+
+// Shader-clock stamps (bench.py: docs_per_sec_per_ghz).  s_memtime counts shader clocks, s_memrealtime a constant 100 MHz; one pair per XCD
+// (the counters are per XCD), written by whichever workgroup of the launch lands there.  Two stamps around a region give the clock the
+// chip HELD over it, weighted by time: d(memtime) / d(memrealtime) x 0.1 GHz.
+__global__ void clock_stamp_kernel(unsigned long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
+    out[2 * xcc] = t;
+    out[2 * xcc + 1] = r;
+}
+
+int ee_clock_stamp(uint64_t* out16_dev, void* stream) {
+    if (!out16_dev) return fail(nullptr, "ee_clock_stamp: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_clock_stamp: no HIP device");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out16_dev, 0, 16 * sizeof(uint64_t), s) != hipSuccess) return fail(nullptr, "ee_clock_stamp: memset failed");
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(out16_dev));
+    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_clock_stamp: launch failed");
     return 0;
 }
 

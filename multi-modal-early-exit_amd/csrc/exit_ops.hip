@@ -480,8 +480,8 @@ void launch_threshold_sweep(const double* conf, const unsigned char* correct, in
             hipLaunchKernelGGL(sweep_thr_kernel, dim3(g2), dim3(256), 0, s, sorted, thr, E1, N, VE, T);
             const int grid = (V + 255) / 256;
             const size_t lds = 64 * 1024;
-            (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_main_kernel<7>), (int)lds);
-            (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&sweep_main_kernel<0>), (int)lds);
+            (void)ensure_dynamic_lds<&sweep_main_kernel<7>>("sweep_main_kernel", (int)lds);
+            (void)ensure_dynamic_lds<&sweep_main_kernel<0>>("sweep_main_kernel", (int)lds);
             if (E1 == 7) hipLaunchKernelGGL((sweep_main_kernel<7>), dim3(grid), dim3(256), lds, s, rec, T, E1, E1P, N, V, acc, mean_exit);
             else hipLaunchKernelGGL((sweep_main_kernel<0>), dim3(grid), dim3(256), lds, s, rec, T, E1, E1P, N, V, acc, mean_exit);
             (void)hipFreeAsync(rec, s); (void)hipFreeAsync(T, s); (void)hipFreeAsync(sorted, s);

@@ -536,14 +536,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const GemmArgs g) 
 template <int EPI, int AMODE>
 static void launch_one_dma(const GemmArgs& a, int grid, hipStream_t s) {
     const size_t lds = gemm_f32_lds_bytes();
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_f32_dma_kernel<EPI, AMODE>), (int)lds);
+    (void)ensure_dynamic_lds<&gemm_f32_dma_kernel<EPI, AMODE>>("gemm_f32_dma_kernel", (int)lds);
     hipLaunchKernelGGL((gemm_f32_dma_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 
 template <int EPI, int AMODE>
 static void launch_one(const GemmArgs& a, int grid, hipStream_t s) {
     const size_t lds = gemm_f32_lds_bytes();
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI, AMODE>), (int)lds);
+    (void)ensure_dynamic_lds<&gemm_f32_kernel<EPI, AMODE>>("gemm_f32_kernel", (int)lds);
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, AMODE>), dim3(grid), dim3(256), lds, s, a);
 }
 

@@ -48,6 +48,7 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
     // wider GEMMs keep eight M-tiles per W tile back to back (QKV, FFN up: unchanged to -0.6 % with N fastest)
     a.tile_order = a.N <= 768 ? 1 : 0;
     // (ahead of the diagnostic library's forced configurations: only these instantiations honour k_splits -- ADVICE r03)
+    if (a.probe) a.terms = 3;      // probes and exit heads keep three terms whatever the caller's mode (a probe shape outside the CfgP list fell through with terms == 1)
     if (a.probe) {      // CLS probe: 128 x 128 tiles under their own kernel name; same MFMA form, k order and term order as CfgC => the same bits
         if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
         if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }

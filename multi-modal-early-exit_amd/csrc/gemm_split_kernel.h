@@ -564,7 +564,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
 template <typename Cfg, int EPI, bool OUT_SPLIT, bool DIAG = false, int TAG = 0, int TERMS = 3>
 static void launch_split_one(const GemmArgs& a, int max_m, int num_cus, hipStream_t s) {
     const size_t lds = Cfg::LOOP_BYTES + 16;
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG, TERMS>), (int)lds);
+    (void)ensure_dynamic_lds<&gemm_split_kernel<Cfg, EPI, OUT_SPLIT, DIAG, TAG, TERMS>>("gemm_split_kernel", (int)lds);
     const int tiles = ((max_m + Cfg::BM - 1) / Cfg::BM) * (a.N / Cfg::BN) * (TAG == 1 && a.k_splits > 1 ? a.k_splits : 1);
     int grid = Cfg::WGS * num_cus;
     if (grid > tiles) grid = tiles;

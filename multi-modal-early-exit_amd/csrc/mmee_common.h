@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 
 namespace mmee {
@@ -20,29 +22,46 @@ inline int diag_env_int(const char* name, int dflt) {
 #endif
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): remembered per device, so a second GPU in the same process
-// gets its opt-in too (the launchers used to keep one process-wide flag), and a failure is returned instead of discarded.
-inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes) {
-    constexpr int kMaxDev = 64, kMaxFn = 96;
-    struct Entry { const void* fn; int bytes[kMaxDev]; };
-    static Entry table[kMaxFn];
-    static int n_fn = 0;
-    static std::mutex mu;
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE).  Round 5: the opt-in is cached PER LAUNCHER
+// INSTANTIATION -- a function-local table of one atomic per device, keyed by the kernel symbol as a template argument -- so a launch costs
+// one hipGetDevice and one relaxed load (no mutex, no search, no table that can fill up: the diagnostic build multiplies instantiations),
+// and a failed opt-in is neither discarded nor left to surface as a generic launch error: it is recorded with the kernel's name and the
+// byte count, and ee_forward / the stand-alone entry points report it (take_lds_error).
+struct LdsOptInError {
+    std::mutex mu;
+    int code = 0;
+    char what[192] = {0};
+};
+inline LdsOptInError& lds_optin_error() {
+    static LdsOptInError e;
+    return e;
+}
+// returns the recorded failure (and clears it), or nullptr
+inline const char* take_lds_error(char* buf, size_t cap) {
+    LdsOptInError& e = lds_optin_error();
+    std::lock_guard<std::mutex> lock(e.mu);
+    if (!e.code) return nullptr;
+    snprintf(buf, cap, "%s", e.what);
+    e.code = 0;
+    return buf;
+}
+template <auto Kernel>
+inline hipError_t ensure_dynamic_lds(const char* name, int bytes) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> granted[kMaxDev];      // zero-initialised: bytes this kernel may use on device d
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    std::lock_guard<std::mutex> lock(mu);
-    Entry* e = nullptr;
-    for (int i = 0; i < n_fn; ++i)
-        if (table[i].fn == kernel) { e = &table[i]; break; }
-    if (!e) {
-        if (n_fn == kMaxFn) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        e = &table[n_fn++];
-        e->fn = kernel;
-        for (int d = 0; d < kMaxDev; ++d) e->bytes[d] = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev;
+    if (known && granted[dev].load(std::memory_order_relaxed) >= bytes) return hipSuccess;
+    const hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (rc == hipSuccess) {
+        if (known) granted[dev].store(bytes, std::memory_order_relaxed);
+    } else {
+        LdsOptInError& e = lds_optin_error();
+        std::lock_guard<std::mutex> lock(e.mu);
+        e.code = (int)rc;
+        snprintf(e.what, sizeof(e.what), "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d bytes) failed for %s on device %d: %s", bytes, name,
+                 dev, hipGetErrorString(rc));
     }
-    if (e->bytes[dev] >= bytes) return hipSuccess;
-    const hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (rc == hipSuccess) e->bytes[dev] = bytes;
     return rc;
 }
 

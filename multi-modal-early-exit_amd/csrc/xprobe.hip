@@ -437,7 +437,7 @@ template <int HEADS, int HH, int RING>
 static void launch_xprobe_attn(const XProbeArgs& a, const XpLayout& L, int grid, hipStream_t s) {
     // per kernel AND device (a process-wide high-water mark left a second device without its opt-in); a failure shows up as the
     // launch error ee_forward reports
-    (void)ensure_dynamic_lds(reinterpret_cast<const void*>(&xprobe_attn_kernel<HEADS, HH, RING>), L.lds);
+    (void)ensure_dynamic_lds<&xprobe_attn_kernel<HEADS, HH, RING>>("xprobe_attn_kernel", L.lds);
     hipLaunchKernelGGL((xprobe_attn_kernel<HEADS, HH, RING>), dim3(grid), dim3(XP_THREADS), L.lds, s, a, L.tstr, L.off_tab, L.off_part, L.off_idx, L.npad);
 }
 

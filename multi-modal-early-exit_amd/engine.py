@@ -188,7 +188,9 @@ class EarlyExitEngine:
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
-                one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False) -> EngineOutput:
+                one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False, out=None) -> EngineOutput:
+        """``out``: optional preallocated ``(logits (B,K) f32, exit_layer (B,) i32, confidence (B,) f32)`` device tensors (contiguous; row
+        slices of larger tensors qualify) the kernels write into instead of fresh allocations -- MicroBatchedEngine hands each half its slice."""
         if not self._finalized:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
@@ -244,9 +246,15 @@ class EarlyExitEngine:
                 raise ValueError(f"temperatures must have {E + 1} entries")
             tmp_c = (C.c_double * (E + 1))(*tm.tolist())
         dev = self.device
-        out_logits = torch.empty((B, K), dtype=torch.float32, device=dev)
-        out_exit = torch.empty((B,), dtype=torch.int32, device=dev)
-        out_conf = torch.empty((B,), dtype=torch.float32, device=dev)
+        if out is not None:
+            out_logits, out_exit, out_conf = out
+            for t, shp, dt in ((out_logits, (B, K), torch.float32), (out_exit, (B,), torch.int32), (out_conf, (B,), torch.float32)):
+                if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous() or t.device != dev:
+                    raise ValueError(f"out: expected a contiguous {dt} tensor of shape {shp} on {dev}")
+        else:
+            out_logits = torch.empty((B, K), dtype=torch.float32, device=dev)
+            out_exit = torch.empty((B,), dtype=torch.int32, device=dev)
+            out_conf = torch.empty((B,), dtype=torch.float32, device=dev)
         nan = float("nan")
         all_logits = torch.full((E + 1, B, K), nan, dtype=torch.float32, device=dev) if want_all else None
         all_crit = torch.full((E + 1, B), nan, dtype=torch.float32, device=dev) if want_all else None
@@ -334,21 +342,59 @@ class EarlyExitEngine:
         return {"gemm": g.value, "attention": a.value, "probe": plan["probe_flops"],
                 "total": g.value + a.value + plan["probe_flops"]}
 
-    def pin_schedule(self, probe_layers=None):
-        """Pin which exit layers are probed first (ee_set_probe_mask).  ``probe_layers``: iterable of 0-based layer indices; ``None``
-        pins the plan the LAST forward ran (synchronises); ``False`` returns to the default (chosen per layer from the stage
-        populations of the most recent finished forward, which makes the launch sequence depend on timing).  Returns the list."""
+    def pin_schedule(self, probe_layers=None, xprobe: Optional[bool] = None):
+        """Pin which exit layers are probed first (ee_set_probe_mask).  The DEFAULT schedule probes every layer that ends in a decision and
+        never changes by itself: the same call always issues the same launches and returns the same bits (round 5; rounds 2-4 let the
+        library choose from whichever earlier forward had finished, a timing-dependent decision).  ``probe_layers``: iterable of 0-based layer
+        indices; ``None`` asks the library's cost model which layers pay, judged from the stage populations of the LAST forward, which must
+        have been a thresholded one (ee_suggest_probe_mask; synchronises), and pins that; ``False`` returns to the default.  Returns the
+        pinned list (None for the default).  The mask is part of the handle's state until changed."""
         if probe_layers is False:
             capi.check(self.lib.ee_set_probe_mask(self._h, 0, 0), self._h, "ee_set_probe_mask")
             return None
         if probe_layers is None:
-            probe_layers = [l for l, d in enumerate(self.layer_plan()["docs_probe"]) if d > 0]
+            xp = self.xprobe_default if xprobe is None else bool(xprobe)
+            m = C.c_uint64()
+            with torch.cuda.device(self.device):
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                capi.check(self.lib.ee_suggest_probe_mask(self._h, capi.FLAG_XPROBE if xp else 0, C.byref(m), stream), self._h,
+                           "ee_suggest_probe_mask")
+            probe_layers = [l for l in range(self.cfg.num_hidden_layers) if (m.value >> l) & 1]
         layers = sorted(int(l) for l in probe_layers)
         mask = 0
         for l in layers:
             mask |= 1 << l
         capi.check(self.lib.ee_set_probe_mask(self._h, 1, mask), self._h, "ee_set_probe_mask")
         return layers
+
+    def set_criterion(self, strategy):
+        """Exit criterion of every later forward ("max_confidence" / "entropy"; ee_set_criterion).  The reference's driver overrides
+        ``model.config.exit_config["inference_strategy"]`` after construction (EE/utils.py:62-78); modeling.py forwards that write here."""
+        from .config import EarlyExitInference
+        st = strategy if isinstance(strategy, EarlyExitInference) else EarlyExitInference(str(strategy))
+        capi.check(self.lib.ee_set_criterion(self._h, st.code), self._h, "ee_set_criterion")
+        self.exit_config.inference_strategy = st
+        return st
+
+    def clock_stamp(self):
+        """Device tensor of 16 int64: per XCD (s_memtime, s_memrealtime) as seen by a one-wave kernel enqueued on the current stream
+        (ee_clock_stamp).  ``clock_ghz(a, b)`` turns two stamps into the shader clock held between them."""
+        t = torch.zeros(16, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(self.lib.ee_clock_stamp(C.c_void_p(t.data_ptr()), stream), None, "ee_clock_stamp")
+        return t
+
+    @staticmethod
+    def clock_ghz(stamp_a, stamp_b):
+        """Mean over the XCDs of d(s_memtime) / d(s_memrealtime) x 0.1 GHz between two ``clock_stamp()`` results (synchronises through .cpu()),
+        and the per-XCD values.  An XCD that a stamp kernel's workgroups did not reach (zeros) is left out."""
+        a, b = stamp_a.cpu().numpy().reshape(8, 2), stamp_b.cpu().numpy().reshape(8, 2)
+        per = []
+        for x in range(8):
+            if a[x, 1] and b[x, 1] and b[x, 1] > a[x, 1]:
+                per.append(0.1 * float(b[x, 0] - a[x, 0]) / float(b[x, 1] - a[x, 1]))
+        return (float(np.mean(per)) if per else None), per
 
     def layer_plan(self):
         """How the last forward ran each encoder layer (ee_last_layer_plan): rows through Q|K|V, rows through the rest of

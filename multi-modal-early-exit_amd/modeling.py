@@ -149,8 +149,19 @@ class LayoutLMv3EEForSequenceClassification:
         e = torch.exp(logits)
         return torch.log(e.sum(1)) - (logits * e).sum(1) / e.sum(1)
 
+    def _sync_exit_config(self):
+        """``load_assets`` writes ``model.config.exit_config["inference_strategy"]`` (and ``["global_threshold"]``) AFTER the model has been
+        built (EE/utils.py:62-78).  The handle was created with the checkpoint's criterion, so the dictionary is re-read at every call and a
+        changed criterion is pushed down (ee_set_criterion); ``early_exit`` reads the threshold from the same dictionary.  A strategy the
+        kernels do not implement (patience / lte) raises, as ``EarlyExitInference.get_sign`` does in the reference."""
+        want = self.config.exit_config["inference_strategy"]
+        want = str(getattr(want, "value", want))
+        if want != str(self.engine.exit_config.inference_strategy):
+            self.engine.set_criterion(want)
+
     # ---- chunked engine call -------------------------------------------------------------------------------------------
     def _run(self, tensors: Dict[str, Any], **kw) -> EngineOutput:
+        self._sync_exit_config()
         B = tensors["pixel_values"].shape[0]
         mb = self.engine.max_docs
         if B <= mb:
@@ -252,6 +263,7 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
     __call__ = forward
 
     def _run(self, tensors, **kw):
+        self._sync_exit_config()
         px = tensors["pixel_values"]
         B, mb = px.shape[0], self.engine.max_docs
         if B <= mb:

@@ -112,4 +112,6 @@ class TorchOracle:
         for j in range(E):
             store[j] = (self.head(gi[j], "classifier") if strategy == "gate" else ex[j]).numpy()
         store[-1] = logits.numpy()
-        return {"logits_store": store, "logits": logits.numpy()}
+        return {"logits_store": store, "logits": logits.numpy(),
+                "exit_logits": np.stack([e.numpy() for e in ex]) if ex else np.zeros((0, B, Kc), np.float32),      # exit_states[j][0]
+                "gate_inputs": np.stack([g.numpy() for g in gi]) if gi else np.zeros((0, B, cfg.hidden_size), np.float32)}

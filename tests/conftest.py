@@ -74,3 +74,27 @@ def matrix_config(pkg, name):
     shape, ee, n_docs, T = MATRIX_CASES[name]
     cfg = pkg.ModelConfig.base(EE_config=ee) if shape == "base" else pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
     return cfg, ee, n_docs, T
+
+
+# ---- round 5: inputs of the fixtures minted from the reference's own sweep / temperature code (tests/golden/make_golden.py "sweep", "temperature")
+def sweep_ref_inputs(seed=2024, E1=7, N=400, K=16):
+    """Seeded synthetic dumped logits (E1, N, K) float64 and labels (N,): later exits are sharper and more often right."""
+    rng = np.random.default_rng(seed)
+    store = rng.standard_normal((E1, N, K)) * np.linspace(1.0, 3.0, E1)[:, None, None]
+    refs = rng.integers(0, K, N)
+    store[:, np.arange(N), refs] += np.linspace(0.5, 3.0, E1)[:, None]
+    return store, refs.astype(np.int64)
+
+
+def temperature_ref_inputs(seed=77, E1=5, N=3000, K=16):
+    """Seeded validation logits (E1, N, K) float64 whose exits are mis-calibrated by different factors, and labels (N,)."""
+    rng = np.random.default_rng(seed)
+    refs = rng.integers(0, K, N)
+    base = rng.standard_normal((E1, N, K))
+    base[:, np.arange(N), refs] += np.linspace(1.0, 3.0, E1)[:, None]
+    gain = np.array([0.4, 1.0, 2.5, 6.0, 0.8])[:E1]          # over- and under-confident exits: optimal temperatures on both sides of 1
+    return base * gain[:, None, None], refs.astype(np.int64)
+
+
+LARGE_GATE_EE = dict(exits=list(range(1, 24)), encoder_layer_strategy="gate", inference_strategy="max_confidence")
+LARGE_GATE_SEEDS = dict(seed_w=41, seed_docs=42)

@@ -10,6 +10,18 @@ Composed reference, all of it code that already exists ou
 The reference's EE_modules imports ``fvcore`` (absent here) at module level without using it on this path; a dummy
 module object is registered for that import only.
 
+Round 5 (``sweep`` / ``temperature`` / ``large``): N3 and N4 pinned to the reference's own code, with these import-time-only stand-ins,
+each an EMPTY module object registered for one ``import`` statement and never called:
+  * ``seaborn``  -- EE/thresh.py:11 (plot helpers; ``check_2D_threshold`` / ``opt0_2D`` / ``opt1`` / ``CSF`` do not touch it),
+  * ``evaluate`` -- EE/metrics.py (imported by EE/generic_scaling.py:5 for ``ece_logits``, which loads the REMOTE metric ``jordyvl/ece``; inside
+    ``TemperatureScaler.set_temperature`` its two results only feed ``print`` lines, EE/generic_scaling.py:84-88, 104-110, so the name is
+    rebound to a function returning NaN: the fitted temperature does not depend on it; ECE itself stays "parity unpinned").
+EE/large_scale.py cannot be imported even so: its ``from utils import ...`` (line 7) executes EE/configs.py, whose module body needs a WORKING
+``sacred.Experiment`` (decorators at import time) -- a functional stand-in, not a stub, so none is written.  ``generate_thresholds`` and
+``check_2D_threshold`` (EE/large_scale.py:42-66) are pure numpy functions of that file: their ``def`` statements (and ``CSF_dict``) are
+compiled FROM THE REFERENCE FILE, read where it lies, into a namespace that holds numpy + scipy's softmax, without executing the module's
+imports -- the code that runs is the reference's text, nothing of it is stored here.
+
 Weights and documents come from ``multi-modal-early-exit_amd.synth`` (numpy-seeded, rebuildable anywhere), so the
 fixtures hold seeds + expected outputs (+ the small tiny-config inputs) instead of hundreds of MB of tensors.
 
@@ -283,6 +295,104 @@ def make_dit_golden():
     print("dit golden done", res["logits"][0, :4])
 
 
+def _stub_module(name):
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    sys.modules.setdefault(name, m)
+    return sys.modules[name]
+
+
+def _reference_defs(path, names):
+    """Compile the named top-level ``def`` / assignment statements of a reference source file (read in place) into a fresh namespace holding
+    numpy, scipy's softmax and OrderedDict -- for pure functions of modules whose import-time machinery cannot run here."""
+    import ast
+    from collections import OrderedDict
+    from scipy.special import softmax
+    src = open(path).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name in names) or
+            (isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id in names for t in n.targets))]
+    assert {getattr(n, "name", None) or n.targets[0].id for n in keep} == set(names), "reference file changed"
+    ns = {"np": np, "softmax": softmax, "OrderedDict": OrderedDict}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def make_sweep_golden():
+    """N3 pinned to the reference: threshold vectors from ``generate_thresholds`` (EE/large_scale.py:53-75, its own
+    ``np.random.seed(42)``, 10 percentiles per exit), exits from ``check_2D_threshold`` (EE/large_scale.py:49-50 and, identically,
+    EE/thresh.py:184-185 -- both are run and must agree), the CSF table from ``CSF_dict["msp"]`` (EE/large_scale.py:12-18), accuracy / mean exit
+    by the two expressions of ``evaluate_exit_logits`` (EE/large_scale.py:88-96).  Extra rows exercise the corner the reference's argmax
+    has: a vector whose LAST threshold no confidence reaches leaves exit 0 for documents no exit fires for (EE/large_scale.py:50)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import sweep_ref_inputs
+    _stub_module("seaborn")
+    import thresh as ref_thresh                                   # EE/thresh.py (imports fine with the seaborn stand-in)
+    ls = _reference_defs(os.path.join(REF, "large_scale.py"), ["CSF_dict", "entropy", "top12_margin_np", "check_2D_threshold", "generate_thresholds"])
+    logits, refs = sweep_ref_inputs()
+    E1, N, K = logits.shape
+    V = 1500
+    ls["num_per_exit"], ls["num_mixtures"] = 10, V              # module globals of the reference's __main__ (EE/large_scale.py:176-177: 10, 1 500 000)
+    thr = np.asarray(ls["generate_thresholds"](logits, refs), dtype=np.float64)
+    assert thr.shape == (V, E1) and (thr[:, -1] == 0).all()
+    conf = np.apply_along_axis(ls["CSF_dict"]["msp"], -1, logits)   # EE/large_scale.py:86: (E1, N)
+    # corner rows: nothing fires anywhere (-> exit 0 for everybody), nothing fires for most, everything fires at exit 0
+    corner = np.array([[1.5] * E1, [0.999] * (E1 - 1) + [1.5], [0.0] * E1, list(np.linspace(0.9, 0.3, E1 - 1)) + [2.0]])
+    thr = np.concatenate([thr, corner], axis=0)
+    exits = np.stack([ls["check_2D_threshold"](conf, t) for t in thr])                      # (V + 4, N)
+    exits2 = np.stack([ref_thresh.check_2D_threshold(conf, t) for t in thr])
+    assert np.array_equal(exits, exits2)
+    assert (exits[V] == 0).all() and (exits[V + 2] == 0).all()
+    correct = (logits.argmax(-1) == refs[None, :])                                          # (E1, N)
+    acc = np.array([np.mean(np.argmax(logits[e, np.arange(N)], axis=-1) == refs) for e in exits])      # EE/large_scale.py:88-91
+    mean_exit = np.array([np.mean(e) for e in exits])                                                   # :92
+    hist = np.stack([np.bincount(e, minlength=E1) for e in exits]).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "sweep_ref.npz"), conf=conf, correct=correct.astype(np.uint8), thresholds=thr, accuracy=acc,
+                        mean_exit=mean_exit, hist=hist, exits_first64=exits[:64].astype(np.int8), exits_corner=exits[V:].astype(np.int8),
+                        n_generated=V, sha_logits=sha(logits))
+    print("sweep_ref", thr.shape, "acc range", acc.min(), acc.max(), "mean exit range", mean_exit.min(), mean_exit.max())
+
+
+def make_temperature_golden():
+    """N4 pinned to the reference: ``TemperatureScaler`` (EE/generic_scaling.py:37-111) fitted per exit exactly as ``calibrate``
+    drives it (EE/eval.py:298-329: ONE scaler object reused over the exits, so every fit is warm-started from the previous exit's
+    temperature; L-BFGS-B on sklearn's log_loss)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import temperature_ref_inputs
+    _stub_module("evaluate")
+    import generic_scaling as gs
+    gs.ece_logits = lambda *a, **k: float("nan")                  # feeds two print lines only (see the header)
+    logits, refs = temperature_ref_inputs()
+    T = gs.TemperatureScaler()
+    temps, nll0, nll1 = [], [], []
+    for e in range(logits.shape[0]):
+        nll0.append(gs.manual_NLL(np.eye(logits.shape[2])[refs], logits[e]))
+        T.fit(refs, logits[e])
+        temps.append(float(T.temperature[0]))
+        nll1.append(gs.manual_NLL(np.eye(logits.shape[2])[refs], T.temperature_scale(logits[e])))
+    np.savez_compressed(os.path.join(HERE, "temperature_ref.npz"), temperature=np.array(temps), nll_before=np.array(nll0),
+                        nll_after=np.array(nll1), sha_logits=sha(logits))
+    print("temperature_ref", temps)
+
+
+def make_large_golden():
+    """BASELINE configs[2] shape from the composed reference: LayoutLMv3-large (H = 1024, L = 24, 16 heads, I = 4096), gate strategy, exits
+    after layers 1..23 + final (EE/models/LayoutLMv3.py:764-792: the policy sees classifier(gate input)), 2 ragged documents at T = 512.
+    CLS rows + exit logits + logits_store only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import LARGE_GATE_EE, LARGE_GATE_SEEDS
+    cfg = pkg.ModelConfig.large(EE_config=LARGE_GATE_EE)
+    W = pkg.synth.make_weights(cfg, seed=LARGE_GATE_SEEDS["seed_w"])
+    docs = pkg.synth.make_documents(cfg, 2, seed=LARGE_GATE_SEEDS["seed_docs"], text_len=512)
+    res = run_reference(cfg, W, docs, LARGE_GATE_EE)
+    policy_fixture(res["logits_store"], [0.0, 0.5, 0.9, 1.0 + 1e-6], "pol", res)
+    keep = {k: v for k, v in res.items() if k not in ("emb_out_row1", "emb_out_lastrow", "layer1_row1")}
+    np.savez_compressed(os.path.join(HERE, "large_gate.npz"), n_docs=2, text_len=512, sha_input_ids=sha(docs["input_ids"]),
+                        sha_pixel_values=sha(docs["pixel_values"]), **LARGE_GATE_SEEDS, **keep)
+    print("large_gate", res["logits_store"].shape, res["logits"][0, :4])
+
+
 def make_matrix_golden():
     """Criterion / head-depth / strategy matrix at the smallest split-precision shape (H = 256) and at base shape: entropy criterion,
     one-layer heads, gates, vision_avg / text_avg exits (EE/models/EE_modules.py:116-160, EE/models/LayoutLMv3.py:70-93, 465-605,
@@ -311,8 +421,17 @@ if __name__ == "__main__":
         make_preprocess_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "dit":
         make_dit_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        make_sweep_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "temperature":
+        make_temperature_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "large":
+        make_large_golden()
     else:
         main()
         make_preprocess_golden()
         make_dit_golden()
         make_matrix_golden()
+        make_sweep_golden()
+        make_temperature_golden()
+        make_large_golden()

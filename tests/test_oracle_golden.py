@@ -195,3 +195,65 @@ def test_hidden_states_restatement_matches_the_reference_rows(pkg, oracle):
     np.testing.assert_allclose(hs[0][:, 1], g["emb_out_row1"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(hs[0][:, -1], g["emb_out_lastrow"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(hs[1][:, 1], g["layer1_row1"], rtol=0, atol=2e-5)
+
+
+# ---- round 5: N3 / N4 and the LayoutLMv3-large shape pinned to the reference's own code (tests/golden/make_golden.py sweep / temperature / large)
+def test_sweep_restatement_matches_reference_vectors(oracle):
+    """EE/large_scale.py:42-96 run in the build container (generate_thresholds with its own np.random.seed(42), check_2D_threshold, the msp CSF)
+    on seeded logits: the oracle's restatement reproduces every exit histogram, accuracy and mean exit bit for bit, including the rows where
+    no exit fires and numpy's argmax returns exit 0 (EE/large_scale.py:50)."""
+    import hashlib
+    from .conftest import load_golden as lg, sweep_ref_inputs
+    g = lg("sweep_ref")
+    logits, refs = sweep_ref_inputs()
+    assert hashlib.sha256(np.ascontiguousarray(logits).tobytes()).hexdigest()[:16] == str(g["sha_logits"])
+    conf, corr = oracle.msp_table(logits, refs)
+    np.testing.assert_allclose(conf, g["conf"], rtol=4e-16, atol=0)            # scipy's softmax against the oracle's: last-bit agreement
+    assert np.array_equal(corr, g["correct"])
+    acc, mex, hist = oracle.threshold_sweep(g["conf"], g["correct"], g["thresholds"])
+    assert np.array_equal(hist, g["hist"])
+    assert np.array_equal(acc, g["accuracy"]) and np.array_equal(mex, g["mean_exit"])
+    V = int(g["n_generated"])
+    assert (g["thresholds"][:V, -1] == 0).all()                                  # the reference leaves the last row at 0 (EE/large_scale.py:56)
+    assert (g["exits_corner"][0] == 0).all() and g["hist"][V, 0] == logits.shape[1]      # nothing fires anywhere -> exit 0 for everybody
+    ex64 = np.stack([(g["conf"] >= t[:, None]).argmax(0) for t in g["thresholds"][:64]])
+    assert np.array_equal(ex64, g["exits_first64"])
+
+
+def test_temperature_restatement_matches_reference_scaler(oracle):
+    """EE/generic_scaling.py:37-111 driven as EE/eval.py:298-329 drives it (one scaler object over the exits): the oracle's L-BFGS-B restatement
+    lands on the reference's temperatures (2e-4 relative: two optimisers' stopping rules, not two objectives)."""
+    from .conftest import load_golden as lg, temperature_ref_inputs
+    g = lg("temperature_ref")
+    logits, refs = temperature_ref_inputs()
+    for e in range(logits.shape[0]):
+        t = oracle.fit_temperature(logits[e], refs)
+        assert abs(t - g["temperature"][e]) <= 2e-4 * g["temperature"][e], (e, t, g["temperature"][e])
+        np.testing.assert_allclose(oracle.nll_at_temperature(logits[e], refs, 1.0), g["nll_before"][e], rtol=1e-12)
+        np.testing.assert_allclose(oracle.nll_at_temperature(logits[e], refs, float(g["temperature"][e])), g["nll_after"][e], rtol=1e-12)
+    assert g["temperature"].min() < 0.5 and g["temperature"].max() > 2.0          # both sides of 1 are exercised
+
+
+def test_large_shape_gate_matches_reference(pkg):
+    """BASELINE configs[2] shape (LayoutLMv3-large: H = 1024, L = 24, 16 heads, I = 4096; gate exits after layers 1..23 + final, S = 709): the
+    torch-CPU restatement the config-3 GPU tests lean on, against the composed reference (stock HF encoder + the reference's LayoutLMv3Exit /
+    classifier wiring of EE/models/LayoutLMv3.py:764-792) on 2 documents."""
+    import hashlib
+    import importlib
+    from .conftest import LARGE_GATE_EE, load_golden as lg
+    g = lg("large_gate")
+    otorch = importlib.import_module("oracle.ee_oracle_torch")
+    cfg = pkg.ModelConfig.large(EE_config=LARGE_GATE_EE)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = pkg.synth.make_documents(cfg, int(g["n_docs"]), seed=int(g["seed_docs"]), text_len=int(g["text_len"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+    assert sha(docs["pixel_values"]) == str(g["sha_pixel_values"]) and sha(docs["input_ids"]) == str(g["sha_input_ids"])
+    out = otorch.TorchOracle(cfg, W).forward_all(docs, LARGE_GATE_EE["exits"], strategy="gate")
+    assert out["logits_store"].shape == (24, 2, 16)
+    np.testing.assert_allclose(out["logits_store"], g["logits_store"], rtol=0, atol=1e-4)          # gated logits: classifier(CLS of layer l)
+    np.testing.assert_allclose(out["exit_logits"], g["exit_logits"], rtol=0, atol=1e-4)            # the 2-way gate heads
+    np.testing.assert_allclose(out["gate_inputs"], g["hidden_cls"][1:24], rtol=0, atol=5e-5)       # CLS rows entering the heads
+    oracle = importlib.import_module("oracle.ee_oracle")
+    for i in range(4):
+        ex, pred, _ = oracle.policy_scan(out["logits_store"], float(g[f"pol_thr{i}"]))
+        assert np.array_equal(ex, g[f"pol_exits{i}"])
