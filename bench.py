@@ -672,7 +672,7 @@ def main(argv=None):
     if stub:
         line["stub_engine"] = True
         line["metric"] = "docs_per_sec (STUB ENGINE on CPU over gloo: rehearsal of the rank body, not a measurement)"
-        line["gathered_checksum"] = float(gathered.double().sum().item())
+        line["gathered_checksum"] = float((g_logits.double().sum() + g_exit.double().sum() + g_conf.double().sum()).item())
 
     if rank == 0 and not a.no_profile and not stub:
         # ---- rooflines, live: HIP events around every launch of one more (untimed) step of the SAME pinned schedule --------------

@@ -186,10 +186,13 @@ int ee_set_probe_mask(ee_handle* h, int32_t enabled, uint64_t mask);
  * caller is going to run with (MMEE_FLAG_XPROBE changes the probe's price).  A pure function of those populations: the caller decides whether
  * to pin the result with ee_set_probe_mask (bench.py and EarlyExitEngine.pin_schedule() do, once, after a warm-up forward). */
 int ee_suggest_probe_mask(ee_handle* h, uint32_t flags, uint64_t* mask_out, void* stream);
-/* Shader-clock stamps: out16_dev (dev uint64[16]) receives, per XCD x, out[2x] = s_memtime (shader clocks) and out[2x + 1] = s_memrealtime
- * (100 MHz) as seen by a one-wave kernel enqueued on `stream`.  Two stamps around a region give the clock the chip HELD over it:
- * d(out[2x]) / d(out[2x + 1]) x 0.1 GHz (bench.py `docs_per_sec_per_ghz`: the boxes of a pool hold different clocks under the same load). */
-int ee_clock_stamp(uint64_t* out16_dev, void* stream);
+/* Shader-clock stamps: out_dev (dev uint64[MMEE_CLOCK_STAMP_WORDS], 16-byte aligned) receives one (s_memtime = shader clocks, s_memrealtime =
+ * 100 MHz) pair PER CU, slot = XCC_ID * 256 + HW_ID[15:8], as seen by one-wave workgroups enqueued on `stream`; slots no workgroup reached stay 0.
+ * Two stamps around a region give the clock the chip HELD over it: mean over the slots filled in both of d(out[2s]) / d(out[2s + 1]) x 0.1 GHz
+ * (the counters of different CUs are not aligned with each other: only same-slot differences mean anything).  bench.py
+ * `docs_per_sec_per_ghz`: the boxes of a pool hold different clocks under the same load. */
+#define MMEE_CLOCK_STAMP_WORDS 4096
+int ee_clock_stamp(uint64_t* out_dev, void* stream);
 
 /* `inputs_embeds` of the reference signature (EE/models/LayoutLMv3.py:383, 414-417 -> LayoutLMv3TextEmbeddings.forward, HF:185-186:
  * "if inputs_embeds is None: inputs_embeds = self.word_embeddings(input_ids)").  embeds: dev float (B,T,H) of the NEXT ee_forward call, read

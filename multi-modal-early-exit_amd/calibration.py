@@ -122,6 +122,14 @@ def calibrate(validation_logits, validation_references, test_logits, device=None
             warnings.warn("calibrate(): the test and validation sets differ in length, so EE/eval.py:321-337 (scaled TEST logits scored "
                           "against the VALIDATION references) cannot be evaluated; the calibration metrics are taken from the scaled "
                           'validation logits instead (metrics_on="validation")', stacklevel=2)
+        else:
+            # equal lengths do not make them the same samples.  The reference-compatible default stays (a drop-in caller gets the
+            # thresholds the reference derives), but never silently: this mode scores TEST predictions against VALIDATION labels.
+            warnings.warn('calibrate(): metrics_on resolved to "reference" because the test and validation sets have the same length: as '
+                          "EE/eval.py:321-337 does, the scaled TEST logits are scored against the VALIDATION references, which only means "
+                          'something when both are the same samples in the same order.  Pass metrics_on="validation" for metrics on the set '
+                          'the temperatures were fitted on, or metrics_on="reference" to state the choice and silence this warning',
+                          stacklevel=2)
     if metrics_on not in ("validation", "reference"):
         raise ValueError('metrics_on must be None, "validation" or "reference"')
     fit = fit_temperatures(validation_logits, validation_references, device=device, with_ece=metrics_on == "validation")

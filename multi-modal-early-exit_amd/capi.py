@@ -19,6 +19,7 @@ FLAG_PROBE_ALWAYS = 8
 FLAG_XPROBE = 16
 FLAG_ONE_TERM = 32
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
+CLOCK_STAMP_WORDS = 4096       # MMEE_CLOCK_STAMP_WORDS
 
 _LIB_NAME = "libmmee_hip.so"
 _LIB_PATH = os.environ.get("MMEE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)

@@ -1409,24 +1409,29 @@ int ee_suggest_probe_mask(ee_handle* h, uint32_t flags, uint64_t* mask_out, void
     return 0;
 }
 
-// Shader-clock stamps (bench.py: docs_per_sec_per_ghz).  s_memtime counts shader clocks, s_memrealtime a constant 100 MHz; one pair per XCD
-// (the counters are per XCD), written by whichever workgroup of the launch lands there.  Two stamps around a region give the clock the
-// chip HELD over it, weighted by time: d(memtime) / d(memrealtime) x 0.1 GHz.
+// Shader-clock stamps (bench.py: docs_per_sec_per_ghz).  s_memtime counts shader clocks, s_memrealtime a constant 100 MHz.  The shader-clock
+// counters of different CUs are NOT aligned with each other (measured, round 5: pairing a stamp taken on one CU with a later stamp taken on
+// another CU of the same XCD gave 1.5 ... 3.3 "GHz" over a few milliseconds), so a stamp records one (s_memtime, s_memrealtime) pair PER CU --
+// slot = XCC_ID x 256 + HW_ID bits 15:8 (CU, shader array, shader engine) -- and two stamps are compared slot by slot: the offsets cancel.
+// 2048 one-wave workgroups, eight per CU on average, so practically every CU is reached by both stamps; the reader skips empty slots.
 __global__ void clock_stamp_kernel(unsigned long long* __restrict__ out) {
     if (threadIdx.x != 0) return;
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);            // HW_REG_HW_ID: CU_ID 11:8, SH_ID 12, SE_ID 15:13
+    const unsigned slot = xcc * 256u + ((hw >> 8) & 255u);
     const unsigned long long t = __builtin_amdgcn_s_memtime(), r = __builtin_amdgcn_s_memrealtime();
-    out[2 * xcc] = t;
-    out[2 * xcc + 1] = r;
+    // several workgroups may land on one CU: the pair is written as one 16-byte store, so whichever wins leaves a consistent pair
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u64x2*>(out + 2 * slot) = u64x2{t, r};
 }
 
-int ee_clock_stamp(uint64_t* out16_dev, void* stream) {
-    if (!out16_dev) return fail(nullptr, "ee_clock_stamp: null argument");
+int ee_clock_stamp(uint64_t* out_dev, void* stream) {
+    if (!out_dev) return fail(nullptr, "ee_clock_stamp: null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_clock_stamp: no HIP device");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(out16_dev, 0, 16 * sizeof(uint64_t), s) != hipSuccess) return fail(nullptr, "ee_clock_stamp: memset failed");
-    hipLaunchKernelGGL(clock_stamp_kernel, dim3(64), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(out16_dev));
+    if (hipMemsetAsync(out_dev, 0, MMEE_CLOCK_STAMP_WORDS * sizeof(uint64_t), s) != hipSuccess) return fail(nullptr, "ee_clock_stamp: memset failed");
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(2048), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(out_dev));
     if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_clock_stamp: launch failed");
     return 0;
 }

@@ -377,9 +377,9 @@ class EarlyExitEngine:
         return st
 
     def clock_stamp(self):
-        """Device tensor of 16 int64: per XCD (s_memtime, s_memrealtime) as seen by a one-wave kernel enqueued on the current stream
-        (ee_clock_stamp).  ``clock_ghz(a, b)`` turns two stamps into the shader clock held between them."""
-        t = torch.zeros(16, dtype=torch.int64, device=self.device)
+        """Device tensor of capi.CLOCK_STAMP_WORDS int64: one (s_memtime, s_memrealtime) pair per CU as seen by one-wave workgroups enqueued on
+        the current stream (ee_clock_stamp).  ``clock_ghz(a, b)`` turns two stamps into the shader clock held between them."""
+        t = torch.zeros(capi.CLOCK_STAMP_WORDS, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             capi.check(self.lib.ee_clock_stamp(C.c_void_p(t.data_ptr()), stream), None, "ee_clock_stamp")
@@ -387,14 +387,17 @@ class EarlyExitEngine:
 
     @staticmethod
     def clock_ghz(stamp_a, stamp_b):
-        """Mean over the XCDs of d(s_memtime) / d(s_memrealtime) x 0.1 GHz between two ``clock_stamp()`` results (synchronises through .cpu()),
-        and the per-XCD values.  An XCD that a stamp kernel's workgroups did not reach (zeros) is left out."""
-        a, b = stamp_a.cpu().numpy().reshape(8, 2), stamp_b.cpu().numpy().reshape(8, 2)
-        per = []
-        for x in range(8):
-            if a[x, 1] and b[x, 1] and b[x, 1] > a[x, 1]:
-                per.append(0.1 * float(b[x, 0] - a[x, 0]) / float(b[x, 1] - a[x, 1]))
-        return (float(np.mean(per)) if per else None), per
+        """(mean GHz, per-XCD mean GHz list) between two ``clock_stamp()`` results (synchronises through .cpu()): d(s_memtime) /
+        d(s_memrealtime) x 0.1 GHz of every CU slot filled in BOTH stamps (the CUs' counters are not aligned with each other, so only
+        same-CU differences are taken), averaged per XCD and over the chip."""
+        a = stamp_a.cpu().numpy().reshape(8, -1, 2).astype(np.float64)
+        b = stamp_b.cpu().numpy().reshape(8, -1, 2).astype(np.float64)
+        ok = (a[..., 1] > 0) & (b[..., 1] > a[..., 1])
+        if not ok.any():
+            return None, []
+        ghz = np.where(ok, 0.1 * (b[..., 0] - a[..., 0]) / np.where(ok, b[..., 1] - a[..., 1], 1.0), 0.0)
+        per = [float(ghz[x][ok[x]].mean()) for x in range(8) if ok[x].any()]
+        return float(ghz[ok].mean()), per
 
     def layer_plan(self):
         """How the last forward ran each encoder layer (ee_last_layer_plan): rows through Q|K|V, rows through the rest of

@@ -38,7 +38,21 @@ def test_gpus_1_runs_in_process():
 def test_gpus_must_match_the_launcher():
     env = dict(_clean_env(), WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-launch"], env=env, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    assert r.returncode != 0
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])          # the refusal is a JSON line with "error", not only a message
+    assert "WORLD_SIZE=2" in d["error"] and d["value"] is None and d["n_gpus"] == 4
+
+
+def test_missing_gpus_fail_loudly_with_a_json_error_line():
+    """`bench.py --gpus N` with fewer than N visible GPUs must not hang, fall back or print a bare message: exit code
+    != 0 and ONE JSON line carrying "error" (64 GPUs exist on no box of the pool, so this runs the same on the CPU container and a GPU box)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "64", "--steps", "1", "--warmup", "0"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert "error" in d and "64" in d["error"] and d["value"] is None and d["n_gpus"] == 64 and d["visible_gpus"] < 64
 
 
 def _stub_expectation(n_gpus, batch, n_job, steps_weak=None):

@@ -464,7 +464,8 @@ def test_calibration_metrics_feed_the_heuristic_end_to_end(pkg, oracle):
     with pytest.raises(ValueError):
         pkg.calibration.calibrate(val, labels, test[:, :-1], metrics_on="reference")
     # the default follows the reference whenever the reference could run (equal lengths), and says so when it cannot
-    _, m_d = pkg.calibration.calibrate(val, labels, test)
+    with pytest.warns(UserWarning, match="VALIDATION references"):      # ... and never silently: equal lengths are not equal samples
+        _, m_d = pkg.calibration.calibrate(val, labels, test)
     assert m_d == m_r
     with pytest.warns(UserWarning):
         _, m_w = pkg.calibration.calibrate(val, labels, test[:, :-1])
@@ -486,14 +487,15 @@ def test_rccl_collectives_of_the_job_at_world_size_one(pkg, tmp_path):
     size 1 (RCCL refuses two ranks on one device -- "Duplicate GPU detected", tools/rccl_same_gpu_probe.py).  It proves RCCL accepts the
     calls as issued (device float64 broadcast / all-reduce MAX, float32 all_gather_into_tensor of padded shards), not that they scale.
     A child process: the process group must not outlive the test."""
-    import subprocess, sys, textwrap
+    import socket, subprocess, sys, textwrap
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()      # a free port (ADVICE r04: 29541 was hard-coded)
     code = textwrap.dedent(f"""
         import importlib, sys, numpy as np
         sys.path.insert(0, {str(ROOT)!r})
         import torch, torch.distributed as dist
         pkg = importlib.import_module("multi-modal-early-exit_amd")
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
         assert dist.get_backend() == "nccl"
         thr = np.array([0.5, 0.25, 0.125, 2.0])
         got = pkg.dist.broadcast_array(thr, 0, device=torch.device("cuda:0"))

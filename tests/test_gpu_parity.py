@@ -505,10 +505,12 @@ def test_xspace_probe_matches_whole_layers_and_goldens(pkg, oracle):
     eng.close()
 
 
-def test_exit_layer_schedule_follows_the_last_forward(pkg, oracle):
-    """Split precision decides per exit layer whether to probe first, from the stage populations of the handle's most recent FINISHED
-    thresholded forward (ee_forward flags, include/mmee.h): with many leavers the exit layer is probed, with hardly any it is run whole,
-    the last layer is probed either way, a dump-all run leaves the history alone — and the results are the same bits in every schedule."""
+def test_exit_layer_schedule_is_pinned_never_inferred(pkg, oracle):
+    """Round 5.  Rounds 2-4 let ee_forward decide per exit layer whether to probe first from the stage populations of the
+    handle's most recent FINISHED forward -- a timing-dependent choice.  Now the schedule is part of the handle's configuration: every layer
+    that ends in a decision by default, whatever ran before (many leavers, hardly any, a dump); the cost model is an explicit query
+    (pin_schedule() -> ee_suggest_probe_mask) whose answer the caller pins; MMEE_FLAG_WHOLE_LAYERS / PROBE_ALWAYS override a pinned mask; and
+    the results are the same bits in every schedule."""
     ee = dict(exits=[2], encoder_layer_strategy="ramp")
     cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=4)
     W = pkg.synth.make_weights(cfg, seed=11, head_gain=6.0)
@@ -528,20 +530,26 @@ def test_exit_layer_schedule_follows_the_last_forward(pkg, oracle):
 
     thr_many, n_many = gap(B // 2)                # about half of the documents leave at layer 2
     thr_few, n_few = gap(B - 2)                   # two or so leave
-    first = eng.forward(*args, thresholds=[thr_many, 2.0])          # no thresholded history yet (the dump does not count): probes
+    first = eng.forward(*args, thresholds=[thr_many, 2.0])
     assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_many]
-    many = eng.forward(*args, thresholds=[thr_many, 2.0])           # history: half leave -> the probe pays
-    torch_sync = eng.stage_counts()
-    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_many] and torch_sync["docs"] == [B, B - n_many]
-    few = eng.forward(*args, thresholds=[thr_few, 2.0])             # still scheduled from the half-leave forward
-    eng.stage_counts()
-    few2 = eng.forward(*args, thresholds=[thr_few, 2.0])            # history: almost nobody leaves -> layer 2 runs whole, the last layer is probed
-    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, B - n_few]
-    whole = eng.forward(*args, thresholds=[thr_few, 2.0], whole_layers=True)
-    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, 0]
+    many = eng.forward(*args, thresholds=[thr_many, 2.0])
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_many] and eng.stage_counts()["docs"] == [B, B - n_many]
+    assert eng.pin_schedule() == [1]              # asked: half leave -> the probe pays; pinned
+    few = eng.forward(*args, thresholds=[thr_few, 2.0])
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_few]       # pinned: what earlier forwards did changes nothing
+    assert eng.pin_schedule() == []               # asked again: almost nobody leaves -> layer 2 should run whole; pinned
+    few2 = eng.forward(*args, thresholds=[thr_few, 2.0])
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, B - n_few]       # ... the last layer is the probe alone either way
+    many2 = eng.forward(*args, thresholds=[thr_many, 2.0])
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, B - n_many]      # still pinned, although half of the documents leave again
     always = eng.forward(*args, thresholds=[thr_few, 2.0], probe_always=True)
     assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_few]
-    for a, b in ((first, many), (few, few2), (few, whole), (few, always)):
+    assert eng.pin_schedule(False) is None
+    dflt = eng.forward(*args, thresholds=[thr_few, 2.0])
+    assert eng.layer_plan()["docs_probe"] == [0, B, 0, B - n_few]       # the default again: every decision layer
+    whole = eng.forward(*args, thresholds=[thr_few, 2.0], whole_layers=True)
+    assert eng.layer_plan()["docs_probe"] == [0, 0, 0, 0]
+    for a, b in ((first, many), (many, many2), (few, few2), (few, whole), (few, always), (few, dflt)):
         assert np.array_equal(_np(a.exit_layer), _np(b.exit_layer)) and np.array_equal(_np(a.logits), _np(b.logits))
         assert np.array_equal(_np(a.confidence), _np(b.confidence))
     assert int((_np(many.exit_layer) == 0).sum()) == n_many and int((_np(few.exit_layer) == 0).sum()) == n_few

@@ -1,5 +1,5 @@
 """Can two ranks on ONE MI355X run the job's RCCL all-gather (backend "nccl")?  (The pool gives this build one GPU; DESIGN section 6 states
-the RCCL path as unexecuted.)  Run: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533
+the RCCL path as unexecuted.)  Run: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port <free port>
 tools/rccl_same_gpu_probe.py      -- prints what RCCL says."""
 import os
 import sys
