@@ -186,6 +186,20 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // (a held ticket starts late: the queue balances worse), six waves per workgroup (192 queries per item, two workgroups per CU, waves 4 and 5
 // issue no DMA: correct, but 13.8 ms -- a workgroup's six waves land 2, 2, 1, 1 on the four SIMDs and a second workgroup of 168-VGPR waves
 // does not fit beside it, so a CU runs six waves instead of twelve).
+// Round 5, the item hand-over (profiles/r05_attention_handover.txt).  Built as two template switches and measured with
+// tools/attn_ab.sh on 256 documents x 12 layers against the shipped form on the same box (9.48 / 9.52 ms):
+//   (1) the NEXT item's ticket drawn by thread 0 in the second-to-last key tile (a compiler-visible atomic whose first use sits right behind the
+//       last tile's full wait) and published through LDS at the last tile's barrier, so an item starts without barrier / atomic / barrier:
+//       bit-identical, 9.61 / 9.63 ms (-1.2 %); on 219-row documents 2.86 against 2.88 ms.  The two other workgroups of the CU already cover
+//       that latency, and the decode + eight more spilled SGPRs cost more than it returns.
+//   (2) on top, the next item's offsets decoded behind the last barrier and its Q fragments fetched behind the last Q K^T MFMA into the SAME
+//       registers (read-write asm operands, one load site per path): 168 VGPRs + 4 spilled, and hipcc splits the live ranges of the 32
+//       in-flight registers at the loop header (v_mov of words that have not landed) -- tools/check_attn_asm.py rejects the build, and the
+//       GPU agrees (max |dlogit| 5.5).  There is no way to tell the register allocator that a register is in flight; 16 index registers
+//       survive it, 48 do not.  LDS staging for the next item's Q needs 32 KB per workgroup where 3.3 KB are free.
+// The "16.8 % of a wave's time is serial per-item work" of round 4 is a per-WAVE share: with three workgroups per CU the SIMD issues other
+// waves meanwhile, so what bounds the kernel is instruction issue (VALU 48 %, matrix pipe 40 % of the cycles), not the item prologue.
+// Removed; the kernel below is the round-4 form.
 constexpr int kXP = 2 | 16;
 // TERMS = 1 (MMEE_FLAG_ONE_TERM, a reported low-precision mode, never a parity path): both products on the hi planes only.
 template <int MODE, bool BIAS, int XP, int TERMS = 3>
