@@ -54,8 +54,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="documents per step per GPU (1024: 22 GB of workspace; the latency-bound parts of a step "
-                                                            "-- CLS probes, exit heads, queue tails -- cost 2 % less per document than at 512)")
+    ap.add_argument("--batch", type=int, default=2048, help="documents per step per GPU.  Round 5: 2048 = two micro-batches of 1024 (the batch of rounds 3-4 per "
+                                                            "handle: 22 GB of workspace each); the latency-bound parts of a step -- CLS probes, exit heads, queue tails -- "
+                                                            "amortise over more documents: +1 % of the matrix-pipe ceiling against 2 x 512 on the same box "
+                                                            "(profiles/r05_micro_batches_ab.txt)")
     ap.add_argument("--total-docs", type=int, default=0,
                     help="strong scaling (BASELINE configs[3]): this many documents in total, dealt round-robin to the ranks; "
                          "--steps is then derived (ceil(shard / batch))")

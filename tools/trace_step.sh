@@ -3,13 +3,13 @@
 #   bash tools/trace_step.sh tag   -> gpurun_out/<tag>_trace.csv  (kernel, start_ns, dur_us)
 set -o pipefail
 TAG=${1:-trace}
-THR=${THR:-0.526068,0.546771,0.506562,0.430061,0.883177}      # thresholds of the default bench (B = 1024, release 0.2)
+THR=${THR:-0.524019,0.542159,0.507206,0.430526,0.883812}      # thresholds of the default bench (round 5: 2 x 1024 documents, release 0.2, calibrated on seed 501234)
 OUT=$PWD/gpurun_out
 ROOT=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/${TAG}_kt
-rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_kt -o t -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --thresholds $THR --probe-layers ${PLAN:-1,3,5,7,9,11} $EXTRA > $OUT/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_kt -o t -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --thresholds $THR --probe-layers ${PLAN:-1,3,5,7,9} $EXTRA > $OUT/${TAG}_kt.log 2>&1
 python3 - "$(find $OUT/${TAG}_kt -name '*kernel_trace.csv' | head -1)" $OUT/${TAG}_trace.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
