@@ -208,6 +208,16 @@ int ee_set_inputs_embeds(ee_handle* h, const float* embeds);
  * the values the reference computes for them under MMEE_FLAG_DENSE_ROWS and zeros in the ragged layout (their rows do not exist there).
  * In MMEE_PREC_F32_SPLIT the values are the hi + lo planes the next layer actually reads (22 significant bits). */
 int ee_set_hidden_states_out(ee_handle* h, float* out);
+/* `head_mask` of the reference signature (EE/models/LayoutLMv3.py:382, 631-641: get_head_mask -> one factor per layer and head, applied as
+ * `attention_probs = attention_probs * head_mask` in LayoutLMv3SelfAttention.forward of transformers 4.26).  mask: dev float (L, heads) of the NEXT ee_forward,
+ * which must carry MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS (what `model.forward` runs); consumed by that call, NULL clears it.  LayoutLMv3 only.
+ * Applied by a side kernel to the context rows behind the fused attention kernel (probs * m @ V == m * (probs @ V)): the hot path is untouched. */
+int ee_set_head_mask(ee_handle* h, const float* mask);
+/* `output_attentions=True` (EE/models/LayoutLMv3.py:157, 219-220, 301: one (B, heads, S, S) tensor of attention probabilities per layer, after the head
+ * mask).  out: dev float (L, B, heads, S, S), S = T + patches + 1, filled by the NEXT ee_forward, which must carry MMEE_FLAG_NO_EXIT |
+ * MMEE_FLAG_WHOLE_LAYERS | MMEE_FLAG_DENSE_ROWS (every position, masked keys with probability 0, as the reference computes them); S <= 1280.
+ * 24 MB per document and layer at S = 709: a debugging / analysis output recomputed by a side kernel, never materialised on the hot path. */
+int ee_set_attentions_out(ee_handle* h, float* out);
 
 /*
  * The policy on a dumped logits array.  logits dev double (E1,N,K); thresholds host double [E1]

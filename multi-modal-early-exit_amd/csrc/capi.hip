@@ -121,6 +121,8 @@ struct ee_handle {
     bool mask_on = false;                         // ee_set_probe_mask: the exit-layer schedule is pinned
     const float* next_inputs_embeds = nullptr;    // ee_set_inputs_embeds: read by the next ee_forward, then cleared
     float* next_hidden_out = nullptr;             // ee_set_hidden_states_out: filled by the next ee_forward, then cleared
+    const float* next_head_mask = nullptr;        // ee_set_head_mask: (L, heads) factors of the next ee_forward, then cleared
+    float* next_attn_out = nullptr;               // ee_set_attentions_out: (L, B, heads, S, S) filled by the next ee_forward, then cleared
     uint64_t probe_mask = 0;
 };
 
@@ -735,8 +737,12 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     // the one-shot side inputs belong to THIS call whether it succeeds or not (a call that fails validation must not leave them armed)
     float* const hs_out = h->next_hidden_out;                  // (L+1, B, T+Pv, H), ee_set_hidden_states_out
     const float* const embeds_in = h->next_inputs_embeds;      // (B, T, H), ee_set_inputs_embeds
+    const float* const head_mask = h->next_head_mask;          // (L, heads), ee_set_head_mask
+    float* const attn_out = h->next_attn_out;                  // (L, B, heads, S, S), ee_set_attentions_out
     h->next_hidden_out = nullptr;
     h->next_inputs_embeds = nullptr;
+    h->next_head_mask = nullptr;
+    h->next_attn_out = nullptr;
     if (!h->finalized) return fail(h, "ee_forward: call ee_finalize after loading the parameters");
     const ee_config& c = h->cfg;
     const bool beit = c.arch == MMEE_ARCH_BEIT;
@@ -747,6 +753,11 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
     if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
+    if ((head_mask || attn_out) && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
+        return fail(h, "ee_forward: head_mask / attention maps exist in dump-all mode with whole layers only (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)");
+    if ((head_mask || attn_out) && beit) return fail(h, "ee_forward: head_mask / attention maps are built for the LayoutLMv3 layers only");
+    if (attn_out && (!(flags & MMEE_FLAG_DENSE_ROWS) || !mmee::attention_probs_supports(T + (c.input_size / c.patch_size) * (c.input_size / c.patch_size) + 1)))
+        return fail(h, "ee_forward: attention maps are (B, heads, S, S) in the padded layout: pass MMEE_FLAG_DENSE_ROWS (S <= 1280)");
     if ((flags & MMEE_FLAG_ONE_TERM) && (beit || !h->split))
         return fail(h, "ee_forward: MMEE_FLAG_ONE_TERM exists for MMEE_PREC_F32_SPLIT LayoutLMv3 handles only");
     if (hs_out && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
@@ -1144,6 +1155,14 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
             AttnArgs at = attn_args();
             at.qkv_doc_off = qkv_off;
             { ProfScope ps(h, P_ATTN, s); run_attn(at); }
+            // side kernels of the reference signature's output_attentions / head_mask (dump-all, whole layers: attention_maps.hip)
+            if (attn_out)
+                mmee::launch_attention_probs(h->QKV, 3 * H, sp ? 1 : 0, mmee::kSplitScaleQKV, h->meta[meta_cur], S_doc_off(cur), h->t1, h->tx, h->ty, h->n1, h->c1,
+                                             h->n2, h->c2, H, c.num_attention_heads, max_len, B, head_mask ? head_mask + (size_t)l * c.num_attention_heads : nullptr,
+                                             attn_out + (size_t)l * B * c.num_attention_heads * max_len * max_len, s);
+            if (head_mask)
+                mmee::launch_head_scale_ctx(h->CTX, H, rp, max_rows, H, head_mask + (size_t)l * c.num_attention_heads, sp ? 1 : 0, mmee::kSplitScaleCtx, cus,
+                                            h->err_flag, s);
             GemmArgs g{};
             g.A = h->CTX; g.lda = H; g.W = sp ? w.ao_s : w.ao_w; g.bias = w.ao_b; g.C = h->Y; g.ldc = H; g.resid = sp ? h->Xs : h->X; g.ldr = H; g.resid_row_src = x_rows;
             g.resid_split_inv = sp ? 1.0f / mmee::kSplitScaleX : 0.f;
@@ -1352,6 +1371,18 @@ int ee_set_inputs_embeds(ee_handle* h, const float* embeds) {
 int ee_set_hidden_states_out(ee_handle* h, float* out) {
     if (!h) return 1;
     h->next_hidden_out = out;
+    return 0;
+}
+
+int ee_set_head_mask(ee_handle* h, const float* mask) {
+    if (!h) return 1;
+    h->next_head_mask = mask;
+    return 0;
+}
+
+int ee_set_attentions_out(ee_handle* h, float* out) {
+    if (!h) return 1;
+    h->next_attn_out = out;
     return 0;
 }
 

@@ -143,6 +143,13 @@ void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, cons
                          const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s);
 // out[doc_orig ? doc_orig[i] : i] = CLS row of active document i; split_inv != 0: X holds split-f16 rows scaled by 1 / split_inv
 // every row of every document -> out[(d * (T + Pv) + position)][H] (ee_set_hidden_states_out); text_dst null: image-only, Pv rows per document
+// attention_maps.hip: side kernels of `output_attentions` / `head_mask` (dump-all, whole layers; never on the hot path)
+bool attention_probs_supports(int S);
+void launch_attention_probs(const float* qkv, int ld, int split, float qkv_scale, const RowMeta* meta, const int* doc_off, const float* t1,
+                            const float* tx, const float* ty, int n1, int c1, int n2, int c2, int H, int heads, int S, int B,
+                            const float* head_scale, float* out, hipStream_t s);
+void launch_head_scale_ctx(float* ctx, int ld, const int* n_rows_ptr, int max_rows, int H, const float* head_scale, int split, float scale,
+                           int num_cus, int* err_flag, hipStream_t s);
 void launch_rows_to_padded(const float* X, float split_inv, int H, int B, int T, int Pv, const int* text_dst, const int* ntext, const int* doc_off,
                            float* out, hipStream_t s);
 void launch_gather_cls(const float* X, int H, const int* x_phys, const int* doc_orig, const int* n_docs_ptr,

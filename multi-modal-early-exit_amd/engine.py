@@ -35,6 +35,7 @@ class EngineOutput:
     head_crit: Optional["torch.Tensor"] = None    # (E,B)    (exit_states[j][1])
     hidden_cls: Optional["torch.Tensor"] = None   # (L+1,B,H)
     hidden_states: Optional["torch.Tensor"] = None   # (L+1,B,T+Pv,H): the state entering every layer and the last layer's output
+    attentions: Optional["torch.Tensor"] = None      # (L,B,heads,T+Pv,T+Pv): attention probabilities of every layer (after the head mask)
 
 
 def _require_torch_cuda(device=None):
@@ -188,7 +189,8 @@ class EarlyExitEngine:
                 temperatures: Optional[Sequence[float]] = None, dump_all: bool = False, dense_rows: bool = False,
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
-                one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False, out=None) -> EngineOutput:
+                one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False, out=None, head_mask=None,
+                want_attentions: bool = False) -> EngineOutput:
         """``out``: optional preallocated ``(logits (B,K) f32, exit_layer (B,) i32, confidence (B,) f32)`` device tensors (contiguous; row
         slices of larger tensors qualify) the kernels write into instead of fresh allocations -- MicroBatchedEngine hands each half its slice."""
         if not self._finalized:
@@ -273,6 +275,28 @@ class EarlyExitEngine:
             whole_layers, dense_rows, xprobe = True, True, False
             S = T + (self.cfg.input_size // self.cfg.patch_size) ** 2 + 1
             hs = torch.empty((self.cfg.num_hidden_layers + 1, B, S, self.cfg.hidden_size), dtype=torch.float32, device=dev)
+        hm = att = None
+        if head_mask is not None or want_attentions:
+            # head_mask / output_attentions of the reference signature (EE/models/LayoutLMv3.py:382-385, 631-641): side kernels of the dump-all,
+            # whole-layers forward (csrc/attention_maps.hip); the fused attention kernels of the hot path never see either
+            if self.beit:
+                raise NotImplementedError("head_mask / attention maps are built for the LayoutLMv3 layers only")
+            if not dump_all:
+                raise ValueError("head_mask / want_attentions need dump_all=True (they belong to model.forward, not to the early-exit path)")
+            whole_layers, xprobe = True, False
+            L_, nh = self.cfg.num_hidden_layers, self.cfg.num_attention_heads
+            if head_mask is not None:
+                # get_head_mask (transformers 4.26 modeling_utils): (heads,) is broadcast over the layers, (L, heads) is taken as is
+                hm = self._dev(head_mask, torch.float32, "head_mask")
+                if hm.dim() == 1:
+                    hm = hm.unsqueeze(0).expand(L_, -1)
+                if tuple(hm.shape) != (L_, nh):
+                    raise ValueError(f"head_mask must be ({nh},) or ({L_}, {nh})")
+                hm = hm.contiguous()
+            if want_attentions:
+                dense_rows = True
+                S = T + (self.cfg.input_size // self.cfg.patch_size) ** 2 + 1
+                att = torch.empty((L_, B, nh, S, S), dtype=torch.float32, device=dev)
         flags = ((capi.FLAG_NO_EXIT if dump_all else 0) | (capi.FLAG_DENSE_ROWS if dense_rows else 0) |
                  (capi.FLAG_WHOLE_LAYERS if whole_layers else 0) | (capi.FLAG_PROBE_ALWAYS if probe_always else 0) |
                  (capi.FLAG_XPROBE if xprobe else 0) | (capi.FLAG_ONE_TERM if one_term else 0))
@@ -288,14 +312,18 @@ class EarlyExitEngine:
                 capi.check(self.lib.ee_set_inputs_embeds(self._h, p(emb)), self._h, "ee_set_inputs_embeds")
             if hs is not None:
                 capi.check(self.lib.ee_set_hidden_states_out(self._h, p(hs)), self._h, "ee_set_hidden_states_out")
+            if hm is not None:
+                capi.check(self.lib.ee_set_head_mask(self._h, p(hm)), self._h, "ee_set_head_mask")
+            if att is not None:
+                capi.check(self.lib.ee_set_attentions_out(self._h, p(att)), self._h, "ee_set_attentions_out")
             rc = self.lib.ee_forward(self._h, p(ids), p(am), p(bb), p(px), p(tt), p(ps), B, T, thr_c, tmp_c, flags,
                                      p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
                                      p(head_logits), p(head_crit), p(hidden), stream)
         capi.check(rc, self._h, "ee_forward")
-        self._keepalive = (ids, am, bb, px, tt, ps, None if self.beit else emb)   # borrowed by the enqueued kernels until the stream drains
+        self._keepalive = (ids, am, bb, px, tt, ps, None if self.beit else emb, hm)   # borrowed by the enqueued kernels until the stream drains
         if validate:
             self.stage_counts()                        # synchronises; raises on out-of-range inputs
-        return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, hs)
+        return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, hs, att)
 
     __call__ = forward
 

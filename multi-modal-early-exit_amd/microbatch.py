@@ -4,8 +4,8 @@ Every kernel of the path is a persistent launch that ends in a partly filled las
 GEMM at the bench shape), and one handle has one forward in flight (its workspace is shared).  ``MicroBatchedEngine`` owns ``n`` handles,
 each sized for ``ceil(max_docs / n)`` documents, and runs a batch as ``n`` contiguous slices on ``n`` HIP streams; a document's arithmetic
 does not depend on which documents share its launches, so the results are the single-handle results BIT FOR BIT under the same exit-layer
-schedule (tests/test_gpu_parity.py::test_micro_batched_engine_is_bit_identical).  Measured round 4 on two plain streams: +1.0 % docs/s
-(DESIGN.md section 8.3); it is what ``bench.py`` runs by default since round 5.
+schedule (tests/test_gpu_round5.py::test_micro_batched_engine_is_bit_identical).  Measured on one box: +0.9 % docs/s at two slices, nothing at
+three, -3 % at four (profiles/r05_micro_batches_ab.txt); it is what ``bench.py`` runs by default since round 5.
 
 Stream semantics are those of ``EarlyExitEngine.forward``: the call only enqueues; the side streams wait for everything the caller's
 current stream holds at the call (inputs, the memory of the output tensors), and the current stream waits for both halves before anything
@@ -107,14 +107,14 @@ class MicroBatchedEngine:
                 cur.wait_event(done)
                 # the optional outputs were allocated on the side stream: their memory must not be handed out again before the current
                 # stream (their reader) has passed this point
-                for t in (parts[-1].all_logits, parts[-1].all_crit, parts[-1].head_logits, parts[-1].head_crit, parts[-1].hidden_cls):
+                for t in (parts[-1].all_logits, parts[-1].all_crit, parts[-1].head_logits, parts[-1].head_crit, parts[-1].hidden_cls, parts[-1].attentions):
                     if t is not None:
                         t.record_stream(cur)
             lo += n
         cat = lambda xs, d: None if xs[0] is None else (xs[0] if len(xs) == 1 else torch.cat(xs, dim=d))
         return EngineOutput(out_logits, out_exit, out_conf, cat([p.all_logits for p in parts], 1), cat([p.all_crit for p in parts], 1),
                             cat([p.head_logits for p in parts], 1), cat([p.head_crit for p in parts], 1),
-                            cat([p.hidden_cls for p in parts], 1), None)
+                            cat([p.hidden_cls for p in parts], 1), None, cat([p.attentions for p in parts], 1))
 
     __call__ = forward
 

@@ -175,7 +175,7 @@ class LayoutLMv3EEForSequenceClassification:
                             cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
                             cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
                             cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1),
-                            cat([p.hidden_states for p in parts], 1))
+                            cat([p.hidden_states for p in parts], 1), cat([p.attentions for p in parts], 1))
 
     # ---- the reference signature -------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, bbox=None, pixel_values=None, labels=None,
@@ -186,13 +186,12 @@ class LayoutLMv3EEForSequenceClassification:
             # EE/models/LayoutLMv3.py:550, with neither input_ids nor inputs_embeds `embedding_output` is at :565)
             raise ValueError("the HIP path implements the multimodal evaluation input: input_ids (or inputs_embeds) AND pixel_values "
                              "(EE/utils.py:93-98); text-only / image-only calls are not built")
-        if head_mask is not None:
-            raise NotImplementedError("head_mask is not part of the evaluation hot path")
-        if output_attentions:
-            raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
+        # head_mask / output_attentions (EE/models/LayoutLMv3.py:382-385, 631-641, 219-220): served by side kernels of this dump-all forward
+        # (csrc/attention_maps.hip); the fused attention kernels of the fast path never materialise a map
         out = self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                              token_type_ids=token_type_ids, position_ids=position_ids, inputs_embeds=inputs_embeds),
-                        dump_all=True, want_all=True, want_head=True, validate=True, want_hidden_states=bool(output_hidden_states))
+                        dump_all=True, want_all=True, want_head=True, validate=True, want_hidden_states=bool(output_hidden_states),
+                        head_mask=head_mask, want_attentions=bool(output_attentions))
         return self._pack(out, labels, return_dict)
 
     def _pack(self, out: EngineOutput, labels, return_dict):
@@ -218,7 +217,8 @@ class LayoutLMv3EEForSequenceClassification:
         exit_criteria.append(out.all_crit[E])                  # :871-872
         # output_hidden_states (EE/models/LayoutLMv3.py:887-896 passes the encoder's tuple through): L + 1 tensors of (B, T + Pv, H)
         hidden_states = None if out.hidden_states is None else tuple(out.hidden_states[l] for l in range(out.hidden_states.shape[0]))
-        res = EESequenceClassifierOutput(loss=loss, logits=logits, hidden_states=hidden_states, attentions=None,
+        attentions = None if out.attentions is None else tuple(out.attentions[l] for l in range(out.attentions.shape[0]))      # L x (B, heads, S, S)
+        res = EESequenceClassifierOutput(loss=loss, logits=logits, hidden_states=hidden_states, attentions=attentions,
                                          exit_losses=exit_losses, exit_criteria=exit_criteria, exit_states=exit_states,
                                          gated_logits=gated)
         if return_dict is False:

@@ -201,8 +201,13 @@ def attention_bias(cfg, W, position_ids: np.ndarray, bbox: np.ndarray) -> np.nda
     return (r1 + (rx + ry)).astype(F32)
 
 
-def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.ndarray) -> np.ndarray:
-    """E1-E3 — one ``LayoutLMv3Layer`` (HF:235-303, 343-368, 485-512)."""
+def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.ndarray, head_mask_l: Optional[np.ndarray] = None,
+                  probs_out: Optional[list] = None) -> np.ndarray:
+    """E1-E3 — one ``LayoutLMv3Layer`` (HF:235-303, 343-368, 485-512).  ``head_mask_l`` (heads,): the layer's slice of ``head_mask``
+    (EE/models/LayoutLMv3.py:185, 631: ``get_head_mask`` -> one factor per layer and head; transformers 4.26 ``LayoutLMv3SelfAttention.forward``
+    applies it as ``attention_probs = attention_probs * head_mask`` after the dropout, before ``attention_probs @ value``; 5.x dropped the
+    argument, so this one line is restated from 4.26 and has no fixture — parity unpinned for ``head_mask``).  ``probs_out``: a list that
+    receives the layer's (masked) attention probabilities (B, heads, S, S), what ``output_attentions=True`` returns (:219-220)."""
     q = f"layoutlmv3.encoder.layer.{l}."
     B, S, H = x.shape
     nh, d = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
@@ -222,6 +227,10 @@ def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.
     z = (sc - mx) * alpha
     ez = np.exp(z - z.max(axis=-1, keepdims=True), dtype=F32)
     probs = (ez / ez.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+    if head_mask_l is not None:
+        probs = (probs * np.asarray(head_mask_l, dtype=F32)[None, :, None, None]).astype(F32)
+    if probs_out is not None:
+        probs_out.append(probs.copy())
     ctx = (probs @ V).transpose(0, 2, 1, 3).reshape(B, S, H)
     a = linear(ctx, W[q + "attention.output.dense.weight"], W[q + "attention.output.dense.bias"])
     a = layer_norm(a + x, W[q + "attention.output.LayerNorm.weight"], W[q + "attention.output.LayerNorm.bias"],
@@ -234,7 +243,8 @@ def encoder_layer(cfg, W, l: int, x: np.ndarray, bias: np.ndarray, ext_mask: np.
 def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exits: Sequence[Union[str, int]],
                 strategy: str = "ramp", criterion: str = "max_confidence", return_hidden_cls: bool = False,
                 return_hidden_states: bool = False,
-                max_layers: Optional[int] = None) -> Dict[str, np.ndarray]:
+                max_layers: Optional[int] = None, head_mask: Optional[np.ndarray] = None,
+                return_attentions: bool = False) -> Dict[str, np.ndarray]:
     """Full-depth forward with every exit evaluated, as the reference does at eval time
     (``LayoutLMv3EEForSequenceClassification.forward`` EE/models/LayoutLMv3.py:696-749, 871-896 ->
     ``LayoutLMv3ModelEE.forward`` :375-665 -> ``LayoutLMv3EncoderEE.forward`` :151-305).
@@ -287,8 +297,13 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
     all_hidden = [x.copy()] if return_hidden_states else None                   # :182-183 (the state ENTERING each layer)
     L = cfg.num_hidden_layers if max_layers is None else max_layers
     k = 0
+    hm = None
+    if head_mask is not None:                                                   # get_head_mask: (heads,) -> every layer; (L, heads) as is
+        hm = np.asarray(head_mask, dtype=F32)
+        hm = np.broadcast_to(hm, (cfg.num_hidden_layers, cfg.num_attention_heads)) if hm.ndim == 1 else hm
+    all_probs = [] if return_attentions else None
     for l in range(L):                                                          # :181
-        x = encoder_layer(cfg, W, l, x, bias, ext)
+        x = encoder_layer(cfg, W, l, x, bias, ext, None if hm is None else hm[l], all_probs)
         cls_rows.append(x[:, 0, :].copy())
         if return_hidden_states:
             all_hidden.append(x.copy())                                         # ... and the last layer's output, :284-285
@@ -320,6 +335,8 @@ def forward_all(cfg, W: Dict[str, np.ndarray], batch: Dict[str, np.ndarray], exi
         out["hidden_cls"] = np.stack(cls_rows)
     if return_hidden_states:
         out["hidden_states"] = np.stack(all_hidden)                             # (L+1, B, T+Pv, H)
+    if return_attentions:
+        out["attentions"] = np.stack(all_probs)                                 # (L, B, heads, T+Pv, T+Pv)
     return out
 
 

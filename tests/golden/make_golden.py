@@ -393,6 +393,27 @@ def make_large_golden():
     print("large_gate", res["logits_store"].shape, res["logits"][0, :4])
 
 
+def make_attentions_golden():
+    """``output_attentions=True`` (EE/models/LayoutLMv3.py:157, 219-220, 301): the attention probabilities of every layer from the stock HF encoder
+    (``LayoutLMv3SelfAttention.forward`` returns ``attention_probs``; transformers 5.15 collects them through its output-capturing hooks) on
+    the tiny configuration -- 3 documents, one of them without padding, S = 48 + 17.  ``head_mask`` has no counterpart in 5.x (the argument was
+    dropped; the reference's 4.26 multiplies the probabilities by it) and therefore no fixture: parity unpinned for that argument."""
+    ee = dict(exits=[1, 3], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=7)
+    docs = pkg.synth.make_documents(cfg, 3, seed=11, text_len=48, min_words=3)
+    docs["attention_mask"][2, :] = 1
+    docs["input_ids"][2, docs["input_ids"][2] == cfg.pad_token_id] = 5
+    m, _ = hf_model(cfg, W, ee)
+    t = {k: torch.from_numpy(v) for k, v in docs.items() if k != "labels"}
+    out = m.layoutlmv3(**t, output_attentions=True)
+    att = torch.stack(list(out.attentions)).numpy()                       # (L, B, heads, S, S)
+    assert att.shape == (cfg.num_hidden_layers, 3, cfg.num_attention_heads, 65, 65)
+    np.savez_compressed(os.path.join(HERE, "tiny_attentions.npz"), seed_w=7, seed_docs=11, text_len=48, n_docs=3, attentions=att,
+                        **{"in_" + k: v for k, v in docs.items()})
+    print("tiny_attentions", att.shape, float(att.sum(-1).min()), float(att.sum(-1).max()))
+
+
 def make_matrix_golden():
     """Criterion / head-depth / strategy matrix at the smallest split-precision shape (H = 256) and at base shape: entropy criterion,
     one-layer heads, gates, vision_avg / text_avg exits (EE/models/EE_modules.py:116-160, EE/models/LayoutLMv3.py:70-93, 465-605,
@@ -427,6 +448,8 @@ if __name__ == "__main__":
         make_temperature_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "large":
         make_large_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "attentions":
+        make_attentions_golden()
     else:
         main()
         make_preprocess_golden()
@@ -435,3 +458,4 @@ if __name__ == "__main__":
         make_sweep_golden()
         make_temperature_golden()
         make_large_golden()
+        make_attentions_golden()

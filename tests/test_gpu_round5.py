@@ -486,3 +486,76 @@ def test_two_ranks_with_different_mixes_run_rank0s_plan(pkg, oracle, tmp_path):
     assert np.array_equal(g["exits"], _np(ref.exit_layer)) and g["exits"].dtype == np.int32
     assert np.array_equal(g["logits"], _np(ref.logits)) and np.array_equal(g["conf"], _np(ref.confidence))
     eng.close()
+
+
+@pytest.mark.parametrize("shape", ["tiny_fp32", "h256_split", "base_split"])
+def test_output_attentions_and_head_mask(pkg, oracle, shape):
+    """VERDICT r04 "missing" 5: the last two arguments of the reference signature (EE/models/LayoutLMv3.py:382-385, 631-641, 219-220).
+    ``output_attentions=True`` returns L tensors (B, heads, S, S) of attention probabilities -- against the stock HF encoder's on the tiny
+    configuration (tests/golden/tiny_attentions.npz) and against the oracle at a split-precision shape and at LayoutLMv3-base; ``head_mask``
+    ((heads,) or (L, heads), as get_head_mask accepts) scales the probabilities and changes the logits as the oracle's restatement of the 4.26
+    line does.  Both are side kernels of the dump-all forward (csrc/attention_maps.hip): `early_exit` refuses them."""
+    import torch
+    if shape == "tiny_fp32":
+        g = load_golden("tiny_attentions")
+        ee = dict(exits=[1, 3], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+        cfg = pkg.ModelConfig.tiny(EE_config=ee)
+        W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+        docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+        T = 48
+    elif shape == "h256_split":
+        g = None
+        ee = dict(exits=[1, 2], encoder_layer_strategy="ramp")
+        cfg = pkg.ModelConfig.tiny(EE_config=ee, hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                                   coordinate_size=48, shape_size=32)
+        W = pkg.synth.make_weights(cfg, seed=5)
+        docs = pkg.synth.make_documents(cfg, 4, seed=6, text_len=48, min_words=3)
+        T = 48
+    else:
+        g = None
+        ee = dict(exits=[2], encoder_layer_strategy="ramp")
+        cfg = pkg.ModelConfig.base(EE_config=ee, num_hidden_layers=3)
+        W = pkg.synth.make_weights(cfg, seed=8)
+        docs = pkg.synth.make_documents(cfg, 2, seed=9, text_len=512)
+        T = 512
+    L, nh = cfg.num_hidden_layers, cfg.num_attention_heads
+    m = pkg.LayoutLMv3EEForSequenceClassification(cfg, weights=W, max_docs=4, max_text_len=T)
+    t = {k: torch.from_numpy(v).cuda() for k, v in docs.items() if k != "labels"}
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], return_attentions=True)
+    out = m.forward(**t, output_attentions=True)
+    assert isinstance(out.attentions, tuple) and len(out.attentions) == L
+    S = T + (cfg.input_size // cfg.patch_size) ** 2 + 1
+    att = np.stack([_np(a) for a in out.attentions])
+    assert att.shape == (L, docs["pixel_values"].shape[0], nh, S, S)
+    err = float(np.abs(att - ref["attentions"]).max())
+    report_measured(f"test_output_attentions_and_head_mask[{shape}]", "max |d attention probability| vs oracle", err)
+    assert err < 2e-6 and abs(float(att.sum(-1).mean()) - 1.0) < 1e-6
+    if g is not None:
+        np.testing.assert_allclose(att, g["attentions"], rtol=0, atol=2e-6)                          # ... and vs the stock HF encoder itself
+    pad = docs["attention_mask"][0] == 0
+    if pad.any():
+        assert (att[:, 0, :, :, :T][..., pad] == 0).all()                                           # masked keys: exactly 0
+    np.testing.assert_allclose(_np(out.logits), ref["logits"], rtol=0, atol=LOGIT_TOL)
+    plain = m.forward(**t)
+    assert plain.attentions is None and np.array_equal(_np(plain.logits), _np(out.logits))       # asking for the maps changes nothing else
+    # head mask: per layer and head, and the (heads,) form broadcast over the layers
+    rng = np.random.default_rng(4)
+    hm = rng.choice([0.0, 1.0, 0.5], size=(L, nh)).astype(np.float32)
+    hm[0, 0] = 0.0
+    for mask in (hm, hm[1]):
+        refm = oracle.forward_all(cfg, W, docs, ee["exits"], return_attentions=True, head_mask=mask)
+        om = m.forward(**t, head_mask=torch.from_numpy(mask), output_attentions=True)
+        np.testing.assert_allclose(np.stack([_np(a) for a in om.attentions]), refm["attentions"], rtol=0, atol=2e-6)
+        e_l = float(np.abs(_np(om.logits) - refm["logits"]).max())
+        report_measured(f"test_output_attentions_and_head_mask[{shape}]", "max |dlogit| under a head mask vs oracle", e_l)
+        assert e_l < LOGIT_TOL
+        for j in range(len(ee["exits"])):
+            np.testing.assert_allclose(_np(om.exit_states[j][0]), refm["exit_logits"][j], rtol=0, atol=LOGIT_TOL)
+        only = m.forward(**t, head_mask=mask)                                                       # numpy mask, no maps
+        assert only.attentions is None and np.array_equal(_np(only.logits), _np(om.logits))
+    assert float(np.abs(_np(om.logits) - _np(out.logits)).max()) > 1e-4                             # the mask really acts
+    with pytest.raises(ValueError):
+        m.engine.forward(**t, thresholds=0.5, head_mask=hm)                                         # not part of the early-exit path
+    with pytest.raises(ValueError):
+        m.forward(**t, head_mask=np.ones((L + 1, nh), np.float32))
+    m.engine.close()

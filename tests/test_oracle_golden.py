@@ -257,3 +257,23 @@ def test_large_shape_gate_matches_reference(pkg):
     for i in range(4):
         ex, pred, _ = oracle.policy_scan(out["logits_store"], float(g[f"pol_thr{i}"]))
         assert np.array_equal(ex, g[f"pol_exits{i}"])
+
+
+def test_attention_probabilities_match_hf(pkg, oracle):
+    """``output_attentions=True``: the oracle's per-layer attention probabilities against the stock HF encoder's (tests/golden/tiny_attentions.npz),
+    masked keys at exactly 0; a head mask (restated from transformers 4.26: probabilities times one factor per layer and head) scales them."""
+    from .conftest import load_golden as lg
+    g = lg("tiny_attentions")
+    ee = dict(exits=[1, 3], encoder_layer_strategy="ramp", inference_strategy="max_confidence")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee)
+    W = pkg.synth.make_weights(cfg, seed=int(g["seed_w"]))
+    docs = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    out = oracle.forward_all(cfg, W, docs, ee["exits"], return_attentions=True)
+    assert out["attentions"].shape == g["attentions"].shape
+    np.testing.assert_allclose(out["attentions"], g["attentions"], rtol=0, atol=2e-6)
+    pad = docs["attention_mask"][0] == 0
+    assert pad.any() and (out["attentions"][:, 0, :, :, :48][..., pad] == 0).all()
+    hm = np.array([[1.0, 0.0], [0.5, 1.0], [1.0, 1.0], [0.0, 2.0]], dtype=np.float32)
+    o2 = oracle.forward_all(cfg, W, docs, ee["exits"], return_attentions=True, head_mask=hm)
+    np.testing.assert_allclose(o2["attentions"][0], out["attentions"][0] * hm[0][None, :, None, None], rtol=0, atol=1e-7)      # layer 0 sees the same input
+    assert (o2["attentions"][3][:, 0] == 0).all() and np.abs(o2["logits"] - out["logits"]).max() > 1e-3
