@@ -84,6 +84,10 @@ def parse(argv=None):
     ap.add_argument("--micro-batches", type=int, default=2,
                     help="slices of a step's batch run on that many handles and HIP streams (MicroBatchedEngine: every kernel's tail overlaps "
                          "the other slice's kernels; bit-identical results); 1 = one handle, one stream")
+    ap.add_argument("--serial-slices", action="store_true",
+                    help="run the micro-batches one after the other on ONE stream (the profiling configuration: under rocprofv3 --kernel-trace two "
+                         "streams make a small kernel's start-to-end time include its wait for the other stream's kernel, so per-kernel durations "
+                         "stop adding up; the roofline's HIP-event step of a normal run is taken the same way)")
     ap.add_argument("--no-extra-rates", action="store_true",
                     help="skip the fixed-work rates beside the headline (full depth with MMEE_FLAG_NO_EXIT, release fractions 0.1 / 0.3)")
     ap.add_argument("--calib-seed-offset", type=int, default=500000,
@@ -459,6 +463,8 @@ def main(argv=None):
     def step(n=None, xprobe=None, **kw):
         sl = (lambda t: t if (t is None or n is None or n == B) else t[:n])
         xp = a.xprobe if xprobe is None else xprobe
+        if a.serial_slices and getattr(eng, "n", 1) > 1:
+            kw.setdefault("serial", True)
         return eng.forward(sl(d_ids), sl(d_am), sl(d_bb), sl(d_px), thresholds=thr, dense_rows=a.dense_rows, temperatures=temps,
                            whole_layers=a.whole_layers, probe_always=a.probe_always, xprobe=bool(xp), **kw)
 
@@ -649,7 +655,7 @@ def main(argv=None):
                    "release_fraction_per_exit": a.release,
                    "thresholds_calibrated_on": ("--thresholds" if a.thresholds else "the timed batch itself" if not a.calib_seed_offset or stub else
                                                 f"a different synthetic batch (seed {a.seed + a.calib_seed_offset}; the timed batch is seed {a.seed})"),
-                   "micro_batches": getattr(eng, "n", 1)},
+                   "micro_batches": getattr(eng, "n", 1), **({"serial_slices": True} if a.serial_slices else {})},
         **({"kv_probe": {"docs_per_sec": kv_probe_rate, "what": "--no-xprobe: probe-first layers read the layer's K | V rows (bit-identical "
                          "to whole layers) instead of the X-space CLS context", "exit_index_equal_to_headline_run": kv_same_exits,
                          "max_abs_dlogit_vs_headline_run": kv_dlogit}} if kv_probe_rate is not None else {}),
@@ -750,7 +756,7 @@ def main(argv=None):
                                 "roles": hb}
 
         if world == 1 and not a.no_traffic:
-            child = ["--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic", "--stream-docs", "0", "--no-extra-rates",
+            child = ["--steps", "1", "--warmup", "0", "--cpu-docs", "0", "--no-profile", "--no-traffic", "--stream-docs", "0", "--no-extra-rates", "--serial-slices",
                      "--micro-batches", str(a.micro_batches), "--batch", str(B), "--precision", eng.precision if eng.precision != "split" else "split", "--workload", a.workload,
                      "--release", str(a.release), "--thresholds", ",".join(repr(float(t)) for t in thr[:-1]),
                      "--probe-layers", ",".join(str(x) for x in (plan_layers or []))]

@@ -43,8 +43,9 @@ def test_model_forward_contract(pkg, name):
     b.pop("labels")
     out2 = m.forward(**b)
     assert out2.loss is None and len(out2.exit_criteria) == 1 and len(out2.gated_logits) == 0
-    with pytest.raises(NotImplementedError):
-        m.forward(**b, output_attentions=True)
+    out_a = m.forward(**b, output_attentions=True)               # EE/models/LayoutLMv3.py:219-220, 301: L tensors (B, heads, S, S); round 5
+    assert len(out_a.attentions) == m.model_config.num_hidden_layers and out2.attentions is None
+    np.testing.assert_allclose(out_a.attentions[0].sum(-1).cpu().numpy(), 1.0, rtol=0, atol=1e-5)
     out3 = m.forward(**b, output_hidden_states=True)             # EE/models/LayoutLMv3.py:887-896: L + 1 tensors of (B, T + Pv, H)
     mc = m.model_config
     L, Bq = mc.num_hidden_layers, b["input_ids"].shape[0]

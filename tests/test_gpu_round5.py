@@ -537,7 +537,9 @@ def test_output_attentions_and_head_mask(pkg, oracle, shape):
         assert (att[:, 0, :, :, :T][..., pad] == 0).all()                                           # masked keys: exactly 0
     np.testing.assert_allclose(_np(out.logits), ref["logits"], rtol=0, atol=LOGIT_TOL)
     plain = m.forward(**t)
-    assert plain.attentions is None and np.array_equal(_np(plain.logits), _np(out.logits))       # asking for the maps changes nothing else
+    # asking for the maps changes nothing else (the maps are written in the padded layout, so that run keeps the pad rows: same values to rounding)
+    assert plain.attentions is None
+    np.testing.assert_allclose(_np(plain.logits), _np(out.logits), rtol=0, atol=2e-5)
     # head mask: per layer and head, and the (heads,) form broadcast over the layers
     rng = np.random.default_rng(4)
     hm = rng.choice([0.0, 1.0, 0.5], size=(L, nh)).astype(np.float32)
@@ -552,7 +554,8 @@ def test_output_attentions_and_head_mask(pkg, oracle, shape):
         for j in range(len(ee["exits"])):
             np.testing.assert_allclose(_np(om.exit_states[j][0]), refm["exit_logits"][j], rtol=0, atol=LOGIT_TOL)
         only = m.forward(**t, head_mask=mask)                                                       # numpy mask, no maps
-        assert only.attentions is None and np.array_equal(_np(only.logits), _np(om.logits))
+        assert only.attentions is None
+        np.testing.assert_allclose(_np(only.logits), _np(om.logits), rtol=0, atol=2e-5)
     assert float(np.abs(_np(om.logits) - _np(out.logits)).max()) > 1e-4                             # the mask really acts
     with pytest.raises(ValueError):
         m.engine.forward(**t, thresholds=0.5, head_mask=hm)                                         # not part of the early-exit path
