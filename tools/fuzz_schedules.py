@@ -56,7 +56,14 @@ def one(case, rng):
             thr[e] = 2.0
         active &= ~(conf[e] > thr[e])
     outs = []
-    for kw in (dict(probe_always=True), dict(whole_layers=True), dict(), dict()):
+    # round 5: the default schedule probes every decision layer and never changes by itself; mixed schedules exist as PINNED masks -- here a
+    # random subset of the layers (outs[3]), then whatever the cost model suggests for the forward before it (outs[4]), then the default again
+    pins = [None, None, None, sorted(rng.choice(np.arange(L), size=int(rng.integers(0, L + 1)), replace=False).tolist()), "suggest", False]
+    for kw, pin in zip((dict(probe_always=True), dict(whole_layers=True), dict(), dict(), dict(), dict()), pins):
+        if pin == "suggest":
+            eng.pin_schedule(None)
+        elif pin is not None:
+            eng.pin_schedule(pin)
         o = eng.forward(*args, thresholds=thr, temperatures=temps, dense_rows=dense, **kw)
         eng.check()
         outs.append((_np(o.exit_layer), _np(o.logits), _np(o.confidence), eng.layer_plan()["docs_probe"]))
@@ -77,7 +84,7 @@ def one(case, rng):
     xrows = eng.layer_plan()["rows_qkv"]
     ok = ok and xok
     print(f"case {case}: L={L} H={H} exits={ee['exits']} {strat} B={B} T={T} dense={dense} temps={temps is not None} "
-          f"left at {np.bincount(ex, minlength=E1).tolist()} probes {outs[0][3]} auto {outs[3][3]} xprobe dlogit "
+          f"left at {np.bincount(ex, minlength=E1).tolist()} probes {outs[0][3]} pinned {outs[3][3]} suggested {outs[4][3]} xprobe dlogit "
           f"{float(np.abs(lgx[~diff] - outs[0][1][~diff]).max(initial=0.0)):.1e} flips {int(diff.sum())} rows_qkv {xrows}: {'ok' if ok else 'MISMATCH'}", flush=True)
     eng.close()
     return ok

@@ -21,18 +21,25 @@ eng.load_weights(pkg.synth.make_weights(cfg, seed=1234, head_gain=6.0))
 d = pkg.synth.make_documents(cfg, B, seed=77, text_len=512)
 args = (d["input_ids"], d["attention_mask"], d["bbox"], d["pixel_values"])
 thr_sets = [[0.52, 0.55, 0.50, 0.43, 0.88, 2.0], [0.3] * 5 + [2.0], [0.99] * 5 + [2.0], [0.6, 0.2, 0.9, 0.4, 0.7, 2.0]]      # E + 1 entries, the last (final classifier) unused
-scheds = {"auto": {}, "probe_always": dict(probe_always=True), "whole": dict(whole_layers=True), "xprobe": dict(xprobe=True, probe_always=True)}
+# round 5: "auto" is the default schedule (every decision layer probed first; nothing is inferred from earlier forwards any more); "pinned" runs
+# under a pinned mixed mask (layers 1 and 7 probed first, 3 / 5 / 9 whole), set right before the call and released behind it
+scheds = {"auto": {}, "probe_always": dict(probe_always=True), "whole": dict(whole_layers=True), "xprobe": dict(xprobe=True, probe_always=True),
+          "pinned": {}}
 first = {}
 t0 = time.time()
 bad = 0
 for i in range(N):
     ti, (sn, skw) = i % len(thr_sets), list(scheds.items())[(i // len(thr_sets)) % len(scheds)]
+    if sn == "pinned":
+        eng.pin_schedule([1, 7])
     out = eng.forward(*args, thresholds=thr_sets[ti], validate=True, **skw)
+    if sn == "pinned":
+        eng.pin_schedule(False)
     key = (sn, ti)
     cur = (out.logits.clone(), out.exit_layer.clone(), out.confidence.clone())
     if key not in first:
         first[key] = cur
-        if sn in ("probe_always", "whole") and ("auto", ti) in first:
+        if sn in ("probe_always", "whole", "pinned") and ("auto", ti) in first:
             ref = first[("auto", ti)]
             if not all(torch.equal(a, b) for a, b in zip(ref, cur)):
                 bad += 1
