@@ -71,7 +71,7 @@ def parse(argv=None):
                          "EE/large_scale.py on the device (N3)")
     ap.add_argument("--dense-rows", action="store_true", help="keep pad rows (A/B switch of the ragged layout)")
     ap.add_argument("--whole-layers", action="store_true", help="run exit layers whole before deciding (A/B switch of probe-first)")
-    ap.add_argument("--probe-always", action="store_true", help="probe first at every exit layer (default: chosen per layer)")
+    ap.add_argument("--probe-always", action="store_true", help="probe first at every exit layer, whatever the cost model suggests (default: the plan ee_suggest_probe_mask prices from a warm-up forward, pinned)")
     ap.add_argument("--xprobe", dest="xprobe", action="store_true", default=True,
                     help="probe-first layers take the CLS context in X space: no Q | K | V for documents that leave (default; "
                          "MMEE_FLAG_XPROBE, built for LayoutLMv3-base shapes, other models run the K | V probe)")

@@ -304,7 +304,7 @@ class EarlyExitEngine:
         # 1e-4 bar by construction, exit indices may flip -- bench.py's `lowprec` field, never a result to rely on
         # xprobe: probe-first layers take the CLS context in X space (no Q | K | V for documents that leave); same exits, logits within
         # tolerance, not bit-identical to whole layers
-        # whole_layers / probe_always pin how exit layers are scheduled (default: chosen per layer from the last forward's exits)
+        # whole_layers / probe_always override the handle's schedule for this call (default: every decision layer probed first, or the mask pin_schedule() set)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)

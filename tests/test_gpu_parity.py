@@ -623,7 +623,7 @@ def test_xspace_probe_config2_exit_set_32_documents_vs_cpu_restatement(pkg, orac
     """The path the bench line runs (MMEE_FLAG_XPROBE, BASELINE configs[1]: LayoutLMv3-base, exits 2/4/6/8/10 + final, ramp, T = 512)
     against the torch-CPU restatement of the reference path on 32 ragged documents: per-exit thresholds in gaps that release about a
     quarter of the documents reaching each exit, so all six stages are populated; exit indices equal, logits within 1e-4 abs, for the
-    X-space probe (pinned at every exit layer and scheduled by the cost model), the K | V probe and whole layers."""
+    X-space probe (flagged at every exit layer and under the default schedule -- since round 5 the same thing), the K | V probe and whole layers."""
     import importlib
     import torch
     otorch = importlib.import_module("oracle.ee_oracle_torch")

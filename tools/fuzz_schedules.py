@@ -1,5 +1,5 @@
 """Randomised cross-check of the exit-layer schedules (GPU box only): for random shapes / exit sets / strategies / thresholds the
-probe-first, whole-layer and automatic schedules and the dump-all rows must agree bit for bit, and the X-space probe within tolerance.  Not a test (minutes); run after touching
+probe-first, whole-layer, default, pinned and cost-model-suggested schedules and the dump-all rows must agree bit for bit, and the X-space probe within tolerance.  Not a test (minutes); run after touching
 the layer loop of csrc/capi.hip:  python tools/fuzz_schedules.py [n_cases [seed]]"""
 import importlib
 import os
