@@ -668,10 +668,11 @@ def main(argv=None):
         "mean_exit_layer": float(layer_of_exit[exits].mean()), "mean_exit_index": float(exits.mean()),
         "exit_distribution": {str(int(layer_of_exit[e])): float((exits == e).mean()) for e in range(len(layer_of_exit))},
         "stage_docs_last_step_rank0": counts["docs"], "executed_tflop_per_step_rank0": fl["total"] / 1e12,
-        "executed_tflops_rank0": fl["total"] / (dt / steps) / 1e12,
+        # (strong scaling: the LAST step is a partial batch, so its flops over the mean step time would mean nothing)
+        "executed_tflops_rank0": None if strong else fl["total"] / (dt / steps) / 1e12,
         # the WHOLE step against the matrix-pipe ceiling of its precision (split: f16 dense peak / 3 terms; fp32: the f32 MFMA peak): every
         # kernel of the step is in the numerator's time, only executed GEMM / attention / probe flops in its work
-        "step_frac_of_ceiling": (fl["total"] / (dt / steps) / 1e12) /
+        "step_frac_of_ceiling": None if strong else (fl["total"] / (dt / steps) / 1e12) /
                                 (PEAK_F32_MFMA_TFLOPS if eng.precision in ("fp32", "f32") else PEAK_F16_MFMA_TFLOPS / SPLIT_TERMS),
     }
     if per_rank is not None:

@@ -12,7 +12,7 @@ while [ $# -gt 0 ]; do
     echo "== $name: $(date +%T)"
     timeout -k 10 "$t" "${cmd[@]}" > "gpurun_out/$name.log" 2>&1
     rc=$?
-    echo "== $name rc=$rc $(date +%T)"; tail -n 5 "gpurun_out/$name.log"
+    echo "== $name rc=$rc $(date +%T)"; tail -n 4 "gpurun_out/$name.log" | cut -c1-240
     if [ $rc -ge 124 ]; then echo "timeout/kill in $name: stopping"; exit $rc; fi
 done
 exit 0
