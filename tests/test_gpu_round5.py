@@ -562,3 +562,36 @@ def test_output_attentions_and_head_mask(pkg, oracle, shape):
     with pytest.raises(ValueError):
         m.forward(**t, head_mask=np.ones((L + 1, nh), np.float32))
     m.engine.close()
+
+
+def test_model_wrapper_with_micro_batches(pkg):
+    """``LayoutLMv3EEForSequenceClassification(..., micro_batches=2)``: the reference-signature ``forward`` (dump-all, every output field, hidden
+    states, attention maps) and ``early_exit`` on two handles / streams return the bits of the one-handle model."""
+    import torch
+    ee = dict(exits=["text_visual_concat", 1, 2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, hidden_size=256, num_attention_heads=4, intermediate_size=512, num_hidden_layers=3,
+                               coordinate_size=48, shape_size=32)
+    W = pkg.synth.make_weights(cfg, seed=7, head_gain=6.0)
+    docs = pkg.synth.make_documents(cfg, 7, seed=11, text_len=48, min_words=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in docs.items() if k != "labels"}
+    one = pkg.LayoutLMv3EEForSequenceClassification(cfg, weights=W, max_docs=8, max_text_len=48)
+    two = pkg.LayoutLMv3EEForSequenceClassification(cfg, weights=W, max_docs=8, max_text_len=48, micro_batches=2)
+    assert type(two.engine).__name__ == "MicroBatchedEngine" and two.engine.split_sizes(7) == [4, 3]
+    a, b = one.forward(**t, labels=torch.from_numpy(docs["labels"])), two.forward(**t, labels=torch.from_numpy(docs["labels"]))
+    assert np.array_equal(_np(a.logits), _np(b.logits)) and float(a.loss) == float(b.loss)
+    for j in range(3):
+        assert np.array_equal(_np(a.exit_states[j][0]), _np(b.exit_states[j][0])) and np.array_equal(_np(a.exit_states[j][1]), _np(b.exit_states[j][1]))
+    ha, hb = one.forward(**t, output_hidden_states=True, output_attentions=True), two.forward(**t, output_hidden_states=True, output_attentions=True)
+    assert len(hb.hidden_states) == 4 and all(np.array_equal(_np(x), _np(y)) for x, y in zip(ha.hidden_states, hb.hidden_states))
+    assert len(hb.attentions) == 3 and all(np.array_equal(_np(x), _np(y)) for x, y in zip(ha.attentions, hb.attentions))
+    crit = np.sort(_np(a.exit_states[1][1]))
+    thr = [2.0, float(0.5 * (crit[3] + crit[4])), 2.0, 2.0]            # three of the seven documents leave at the first encoder exit
+    ea, eb = one.early_exit(**t, thresholds=thr), two.early_exit(**t, thresholds=thr)
+    for x, y in zip((ea.logits, ea.exit_layer, ea.confidence), (eb.logits, eb.exit_layer, eb.confidence)):
+        assert np.array_equal(_np(x), _np(y))
+    assert len(np.unique(_np(eb.exit_layer))) >= 2
+    two.config.exit_config["inference_strategy"] = "entropy"            # the override reaches both handles
+    one.config.exit_config["inference_strategy"] = "entropy"
+    assert np.array_equal(_np(one.forward(**t).exit_states[0][1]), _np(two.forward(**t).exit_states[0][1]))
+    one.engine.close()
+    two.engine.close()
