@@ -61,7 +61,9 @@ enum { MMEE_DT_F32 = 0, MMEE_DT_F16 = 1, MMEE_DT_BF16 = 2 };
 /* ee_forward flags */
 enum {
     MMEE_FLAG_DENSE_ROWS = 1,  /* keep all T text rows per document (pad rows computed, masked as keys) instead of the
-                                  ragged layout that drops pad rows; results are identical, this is the A/B switch  */
+                                  ragged layout that drops pad rows; the two layouts agree to ROUNDING (<= 2e-5 on
+                                  logits: the attention sums a row's keys in tiles whose boundaries differ), not
+                                  to the bit; exit indices are equal.  This is the A/B switch                    */
     MMEE_FLAG_NO_EXIT = 2,     /* dump-all mode: evaluate every exit for every document, nobody leaves early
                                   (the reference's own behaviour, EE/utils.py:63-71 "impossible thresholds")        */
     MMEE_FLAG_WHOLE_LAYERS = 4,/* run every encoder layer whole before its exit decision (what the reference does,
@@ -152,6 +154,33 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
                int32_t B, int32_t T, const double* thresholds, const double* temperatures, uint32_t flags,
                float* out_logits, int32_t* out_exit, float* out_conf, float* out_all_logits, float* out_all_crit,
                float* out_head_logits, float* out_head_crit, float* out_hidden_cls, void* stream);
+
+/*
+ * The same forward as a captured launch list (hipGraph), for callers that keep the reference's small batches (eval_batch_size = 1,
+ * EE/configs.py:36; the loop EE/utils.py:169-193 issues one forward per document): ~185 launches per forward become one graph launch.
+ *
+ * ee_graph_capture takes EXACTLY the arguments of ee_forward.  It runs the call once eagerly on `stream` (argument validation, one-time kernel
+ * set-up; the outputs hold that call's results), synchronises, then captures the same launch list and instantiates it; *graph_id names it.
+ * The graph is bound to the POINTERS it was captured with -- inputs and outputs are static buffers the caller refills / reads between
+ * replays -- and to (B, T, flags, which outputs were non-NULL) and to the handle's exit-layer schedule at capture time (ee_set_probe_mask).
+ * Thresholds and temperatures are NOT baked in: the decide kernels read them from a device vector that every ee_graph_launch refreshes.
+ * `stream` must be a created stream (the legacy null stream cannot be captured).  Not capturable: the one-shot side inputs / outputs
+ * (ee_set_inputs_embeds, ee_set_hidden_states_out, ee_set_head_mask, ee_set_attentions_out) and an armed ee_profile.
+ *
+ * ee_graph_launch replays it on `stream` (any stream, the null stream included) with this launch's thresholds (host double [E+1]; may be NULL
+ * for a graph captured with MMEE_FLAG_NO_EXIT) and temperatures (host double [E+1] or NULL = 1.0: a division by 1.0 is exact, so a graph
+ * replayed without temperatures returns the bits of the eager call without them).  Same arithmetic, same launch order, same bits as
+ * ee_forward on the same inputs (tests/test_gpu_round6.py).  Error reporting, ee_last_stage_counts, ee_last_flops and ee_last_layer_plan work
+ * as after ee_forward.  Rows of out_all_* / out_head_* that a replay does not reach keep what the buffers held before (as ee_forward).
+ * ee_graph_destroy releases the executable graph (ee_destroy releases all of them).
+ */
+int ee_graph_capture(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
+                     const float* pixel_values, const int64_t* token_type_ids, const int64_t* position_ids,
+                     int32_t B, int32_t T, const double* thresholds, const double* temperatures, uint32_t flags,
+                     float* out_logits, int32_t* out_exit, float* out_conf, float* out_all_logits, float* out_all_crit,
+                     float* out_head_logits, float* out_head_crit, float* out_hidden_cls, void* stream, int32_t* graph_id);
+int ee_graph_launch(ee_handle* h, int32_t graph_id, const double* thresholds, const double* temperatures, void* stream);
+int ee_graph_destroy(ee_handle* h, int32_t graph_id);
 
 /* Per-stage statistics of the last ee_forward (synchronises with `stream`): active documents and packed rows entering
  * each of the E+1 exit stages.  n_stages_out receives E+1. */

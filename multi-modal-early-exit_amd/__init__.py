@@ -7,7 +7,7 @@ from . import config, synth  # noqa: F401
 from .config import (EarlyExitHead, EarlyExitInference, EarlyExitStrategy, ExitConfig, ModelConfig,  # noqa: F401
                      POSSIBLE_EXITS, parse_exits)
 from . import capi  # noqa: F401,E402
-from .engine import EarlyExitEngine, EngineOutput, load_checkpoint_tensors, save_checkpoint  # noqa: F401,E402
+from .engine import CapturedForward, EarlyExitEngine, EngineOutput, load_checkpoint_tensors, save_checkpoint  # noqa: F401,E402
 from .microbatch import MicroBatchedEngine  # noqa: F401,E402
 from .modeling import (DiTEEForImageClassification, EEModelOutput, EESequenceClassifierOutput,  # noqa: F401,E402
                        LayoutLMv3EEForSequenceClassification, load_local_processor)

@@ -65,6 +65,10 @@ SYMBOLS = {
     "ee_expected_tensor_name": (C.c_char_p, [_vp, _i32]),
     "ee_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(C.c_double),
                              C.POINTER(C.c_double), _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ee_graph_capture": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i32)]),
+    "ee_graph_launch": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
+    "ee_graph_destroy": (C.c_int, [_vp, _i32]),
     "ee_last_stage_counts": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(_i32), _vp]),
     "ee_last_flops": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp]),
     "ee_last_layer_plan": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _i32, C.POINTER(C.c_double), _vp]),

@@ -124,6 +124,20 @@ struct ee_handle {
     const float* next_head_mask = nullptr;        // ee_set_head_mask: (L, heads) factors of the next ee_forward, then cleared
     float* next_attn_out = nullptr;               // ee_set_attentions_out: (L, B, heads, S, S) filled by the next ee_forward, then cleared
     uint64_t probe_mask = 0;
+    // captured-graph forms of ee_forward (ee_graph_capture): the launch list of one (inputs, B, T, flags, outputs) configuration as a hipGraphExec;
+    // thresholds / temperatures live in a device buffer the decide kernels read, refreshed in front of every replay
+    struct GraphRec {
+        hipGraphExec_t exec = nullptr;
+        double* thr_dev = nullptr;                // [2 * (E + 1)]: thresholds, then temperatures (1.0 when the launch passes none)
+        int n_exits1 = 0;
+        bool no_exit = false;
+        // bookkeeping of the captured forward, restored by every launch (ee_last_stage_counts / ee_last_flops / ee_last_layer_plan read it)
+        int last_B = 0, last_T = 0, last_stages = 0;
+        uint32_t last_flags = 0;
+        bool last_gate_heads = true;
+        std::vector<int> layer_stage, layer_qkv_stage, layer_probe_stage, layer_xprobe, exit_stage;
+    };
+    std::vector<GraphRec> graphs;
 };
 
 namespace {
@@ -144,6 +158,16 @@ int fail(ee_handle* h, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) return fail(h, "%s failed: %s", #expr, hipGetErrorString(e_));     \
     } while (0)
+
+// What every entry point that launches kernels returns through: a failed dynamic-LDS opt-in of one of ITS launchers (recorded per thread,
+// mmee_common.h) with the kernel's name, else the launch error, else 0.
+int launch_status(ee_handle* h, const char* who) {
+    char lds_msg[192];
+    if (mmee::take_lds_error(lds_msg, sizeof(lds_msg))) { (void)hipGetLastError(); return fail(h, "%s: %s", who, lds_msg); }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, "%s: launch failed: %s", who, hipGetErrorString(e));
+    return 0;
+}
 
 // Error flags of forwards that were enqueued earlier and not reported yet, oldest first.  wait = false: only forwards that have finished
 // (stops at the first one still running: one handle's forwards finish in order); wait = true: waits for each.  all = false: returns at
@@ -565,6 +589,7 @@ int ee_destroy(ee_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& ev : h->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (h->fwd_done) (void)hipEventDestroy(h->fwd_done);
     if (h->err_host) (void)hipHostFree(h->err_host);
     for (auto& es : h->errs) if (es.done) (void)hipEventDestroy(es.done);
@@ -728,11 +753,56 @@ int ee_finalize(ee_handle* h) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
+}  // extern "C"
+
+namespace {
+
+__global__ void set_thresholds_kernel(ThrPack p, double* __restrict__ dst) {
+    for (int i = threadIdx.x; i < p.n; i += blockDim.x) dst[i] = p.v[i];
+}
+
+// What ee_forward and ee_graph_launch do in FRONT of the launch list: errors of earlier forwards (every finished one is looked at now; the
+// slot this forward will use is waited for if need be), and the wait for the previous forward when it ran on another stream.
+int forward_pre(ee_handle* h, hipStream_t s) {
+    if (!h->fwd_done) HIP_OK(h, hipEventCreateWithFlags(&h->fwd_done, hipEventDisableTiming));
+    if (!h->err_host) {
+        HIP_OK(h, hipHostMalloc((void**)&h->err_host, sizeof(int) * ee_handle::kErrSlots, hipHostMallocDefault));
+        memset(h->err_host, 0, sizeof(int) * ee_handle::kErrSlots);
+        for (auto& es : h->errs) HIP_OK(h, hipEventCreateWithFlags(&es.done, hipEventDisableTiming));
+    }
+    {
+        int e = take_errors(h, false, false);
+        ee_handle::ErrSlot& mine = h->errs[h->err_seq % ee_handle::kErrSlots];
+        if (!e && mine.pending) {
+            (void)hipEventSynchronize(mine.done);
+            e = take_errors(h, false, false);
+        }
+        if (e) return report_errors(h, e, "a PREVIOUS forward on this handle");
+    }
+    if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
+    return 0;
+}
+
+// ... and BEHIND it: the forward's error word into its own pinned slot, the events later calls wait on.
+int forward_post(ee_handle* h, hipStream_t s) {
+    const int k = (int)(h->err_seq % ee_handle::kErrSlots);
+    HIP_OK(h, hipMemcpyAsync(h->err_host + k, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipEventRecord(h->errs[k].done, s));
+    h->errs[k].pending = true;
+    ++h->err_seq;
+    HIP_OK(h, hipEventRecord(h->fwd_done, s));
+    h->last_stream = s; h->has_fwd = true;
+    return 0;
+}
+
+// The launch list of one forward.  cap == nullptr: the eager call (thresholds / temperatures are kernel arguments).  cap != nullptr: the call
+// is being CAPTURED into a graph -- only enqueue operations are issued (no event, no host copy, no profiling), and the decide kernels read
+// thresholds and temperatures from cap->thr_dev, so that one captured launch list serves every later threshold vector.
+int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
                const float* pixel_values, const int64_t* token_type_ids, const int64_t* position_ids, int32_t B, int32_t T,
                const double* thresholds, const double* temperatures, uint32_t flags, float* out_logits, int32_t* out_exit,
                float* out_conf, float* out_all_logits, float* out_all_crit, float* out_head_logits, float* out_head_crit,
-               float* out_hidden_cls, void* stream) {
+               float* out_hidden_cls, void* stream, const ee_handle::GraphRec* cap) {
     if (!h) return 1;
     // the one-shot side inputs belong to THIS call whether it succeeds or not (a call that fails validation must not leave them armed)
     float* const hs_out = h->next_hidden_out;                  // (L+1, B, T+Pv, H), ee_set_hidden_states_out
@@ -752,7 +822,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     if (B < 1 || B > c.max_docs) return fail(h, "ee_forward: B=%d outside [1, max_docs=%d]", B, c.max_docs);
     if (!beit && (T < 1 || T > c.max_text_len)) return fail(h, "ee_forward: T=%d outside [1, max_text_len=%d]", T, c.max_text_len);
     const int E = c.n_embedding_exits + c.n_encoder_exits;
-    if (!thresholds && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
+    if (!thresholds && !cap && !(flags & MMEE_FLAG_NO_EXIT)) return fail(h, "ee_forward: thresholds required unless MMEE_FLAG_NO_EXIT");
     if ((head_mask || attn_out) && (flags & (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)) != (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS))
         return fail(h, "ee_forward: head_mask / attention maps exist in dump-all mode with whole layers only (MMEE_FLAG_NO_EXIT | MMEE_FLAG_WHOLE_LAYERS)");
     if ((head_mask || attn_out) && beit) return fail(h, "ee_forward: head_mask / attention maps are built for the LayoutLMv3 layers only");
@@ -778,22 +848,10 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     auto S_x_src = [&](int st) { return h->x_src + st * sstride; };
     auto S_meta_src = [&](int st) { return h->meta_src + st * sstride; };
 
-    if (!h->fwd_done) HIP_OK(h, hipEventCreateWithFlags(&h->fwd_done, hipEventDisableTiming));
-    if (!h->err_host) {
-        HIP_OK(h, hipHostMalloc((void**)&h->err_host, sizeof(int) * ee_handle::kErrSlots, hipHostMallocDefault));
-        memset(h->err_host, 0, sizeof(int) * ee_handle::kErrSlots);
-        for (auto& es : h->errs) HIP_OK(h, hipEventCreateWithFlags(&es.done, hipEventDisableTiming));
-    }
-    {   // errors of earlier forwards: every finished one is looked at now; the slot this forward will use is waited for if need be
-        int e = take_errors(h, false, false);
-        ee_handle::ErrSlot& mine = h->errs[h->err_seq % ee_handle::kErrSlots];
-        if (!e && mine.pending) {
-            (void)hipEventSynchronize(mine.done);
-            e = take_errors(h, false, false);
-        }
-        if (e) return report_errors(h, e, "a PREVIOUS forward on this handle");
-    }
-    if (h->has_fwd && s != h->last_stream) HIP_OK(h, hipStreamWaitEvent(s, h->fwd_done, 0));
+    if (cap && (hs_out || embeds_in || head_mask || attn_out || h->prof_on))
+        return fail(h, "ee_graph_capture: the one-shot side inputs / outputs (inputs_embeds, hidden states, head mask, attention maps) and ee_profile "
+                       "belong to eager calls");
+    if (!cap) { const int rc_pre = forward_pre(h, s); if (rc_pre) return rc_pre; }
     HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
     HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
     h->next_queue_head = 0;
@@ -987,6 +1045,7 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
         d.pol_logits = pol; d.head_logits = head; d.K = K; d.Kh = Kh;
         d.thr = thresholds ? thresholds[exit_index] : 0.0;
         d.temp = temperatures ? temperatures[exit_index] : 1.0;
+        if (cap) { d.thr_ptr = cap->thr_dev; d.temp_ptr = cap->thr_dev + (E + 1); }      // replays read the vector of THEIR launch
         d.criterion = c.criterion; d.is_final = is_final ? 1 : 0; d.no_exit = no_exit ? 1 : 0; d.exit_index = exit_index; d.B = B;
         d.counts = &h->counts[cur]; d.doc_orig = S_doc_orig(cur); d.doc_off = S_doc_off(cur); d.x_phys = x_phys;
         d.n_counts = &h->counts[cur + 1]; d.n_doc_orig = S_doc_orig(cur + 1); d.n_doc_off = S_doc_off(cur + 1);
@@ -1330,20 +1389,102 @@ int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_
     }
     h->last_B = B; h->last_T = T; h->last_stages = E + 1; h->last_flags = flags;
     h->last_gate_heads = out_head_logits || out_head_crit;
+    if (!cap) { const int rc_post = forward_post(h, s); if (rc_post) return rc_post; }
+    return launch_status(h, cap ? "ee_graph_capture" : "ee_forward");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ee_forward(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox,
+               const float* pixel_values, const int64_t* token_type_ids, const int64_t* position_ids, int32_t B, int32_t T,
+               const double* thresholds, const double* temperatures, uint32_t flags, float* out_logits, int32_t* out_exit,
+               float* out_conf, float* out_all_logits, float* out_all_crit, float* out_head_logits, float* out_head_crit,
+               float* out_hidden_cls, void* stream) {
+    return forward_body(h, input_ids, attention_mask, bbox, pixel_values, token_type_ids, position_ids, B, T, thresholds, temperatures, flags,
+                        out_logits, out_exit, out_conf, out_all_logits, out_all_crit, out_head_logits, out_head_crit, out_hidden_cls, stream, nullptr);
+}
+
+// ---- captured-graph form of the forward (round 6) ------------------------------------------------------------------
+// The reference evaluates at batch size 1 (EE/configs.py:36; loop EE/utils.py:169-193): ~185 launches per forward, each a few microseconds of
+// GPU work.  ee_forward only enqueues, every kernel reads its extent from device memory, and since round 5 the launch list is a pure function of
+// the handle's configuration and the call's (B, T, flags, outputs) -- so ONE capture is valid for every later batch in the same buffers.
+int ee_graph_capture(ee_handle* h, const int64_t* input_ids, const int64_t* attention_mask, const int64_t* bbox, const float* pixel_values,
+                     const int64_t* token_type_ids, const int64_t* position_ids, int32_t B, int32_t T, const double* thresholds,
+                     const double* temperatures, uint32_t flags, float* out_logits, int32_t* out_exit, float* out_conf, float* out_all_logits,
+                     float* out_all_crit, float* out_head_logits, float* out_head_crit, float* out_hidden_cls, void* stream, int32_t* graph_id) {
+    if (!h || !graph_id) return fail(h, "ee_graph_capture: null argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!s) return fail(h, "ee_graph_capture: the legacy null stream cannot be captured; pass a created stream");
+    const int E1 = h->cfg.n_embedding_exits + h->cfg.n_encoder_exits + 1;
+    // (1) the same call, eagerly: it validates the arguments, makes every kernel's one-time set-up (dynamic-LDS opt-ins) happen outside the
+    // capture, and leaves its results in the output buffers
+    int rc = forward_body(h, input_ids, attention_mask, bbox, pixel_values, token_type_ids, position_ids, B, T, thresholds, temperatures, flags,
+                          out_logits, out_exit, out_conf, out_all_logits, out_all_crit, out_head_logits, out_head_crit, out_hidden_cls, stream, nullptr);
+    if (rc) return rc;
+    HIP_OK(h, hipStreamSynchronize(s));
     {
-        const int k = (int)(h->err_seq % ee_handle::kErrSlots);
-        HIP_OK(h, hipMemcpyAsync(h->err_host + k, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_OK(h, hipEventRecord(h->errs[k].done, s));
-        h->errs[k].pending = true;
-        ++h->err_seq;
+        const int e = take_errors(h, true, true);
+        if (e) return report_errors(h, e, "the warm-up forward of ee_graph_capture");
     }
-    HIP_OK(h, hipEventRecord(h->fwd_done, s));
-    h->last_stream = s; h->has_fwd = true;
-    {
-        char lds_msg[192];
-        if (mmee::take_lds_error(lds_msg, sizeof(lds_msg))) { (void)hipGetLastError(); return fail(h, "ee_forward: %s", lds_msg); }
+    ee_handle::GraphRec g;
+    g.n_exits1 = E1;
+    g.no_exit = (flags & MMEE_FLAG_NO_EXIT) != 0;
+    if (dev_alloc(h, &g.thr_dev, (size_t)2 * E1)) return 1;
+    // (2) the launch list again, captured
+    hipGraph_t graph = nullptr;
+    HIP_OK(h, hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    rc = forward_body(h, input_ids, attention_mask, bbox, pixel_values, token_type_ids, position_ids, B, T, thresholds, temperatures, flags,
+                      out_logits, out_exit, out_conf, out_all_logits, out_all_crit, out_head_logits, out_head_crit, out_hidden_cls, stream, &g);
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph) return fail(h, "ee_graph_capture: hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail(h, "ee_graph_capture: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    g.last_B = h->last_B; g.last_T = h->last_T; g.last_stages = h->last_stages; g.last_flags = h->last_flags; g.last_gate_heads = h->last_gate_heads;
+    g.layer_stage = h->layer_stage; g.layer_qkv_stage = h->layer_qkv_stage; g.layer_probe_stage = h->layer_probe_stage;
+    g.layer_xprobe = h->layer_xprobe; g.exit_stage = h->exit_stage;
+    h->graphs.push_back(g);
+    *graph_id = (int32_t)h->graphs.size() - 1;
+    return 0;
+}
+
+int ee_graph_launch(ee_handle* h, int32_t graph_id, const double* thresholds, const double* temperatures, void* stream) {
+    if (!h) return 1;
+    if (graph_id < 0 || graph_id >= (int32_t)h->graphs.size() || !h->graphs[graph_id].exec) return fail(h, "ee_graph_launch: no such graph (%d)", graph_id);
+    const ee_handle::GraphRec& g = h->graphs[graph_id];
+    if (!thresholds && !g.no_exit) return fail(h, "ee_graph_launch: thresholds required (the graph was captured without MMEE_FLAG_NO_EXIT)");
+    if (h->prof_on) return fail(h, "ee_graph_launch: ee_profile times eager launches; disarm it first");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rc_pre = forward_pre(h, s);
+    if (rc_pre) return rc_pre;
+    ThrPack p{};
+    p.n = 2 * g.n_exits1;
+    for (int i = 0; i < g.n_exits1; ++i) {
+        p.v[i] = thresholds ? thresholds[i] : 0.0;
+        p.v[g.n_exits1 + i] = temperatures ? temperatures[i] : 1.0;
     }
-    HIP_OK(h, hipGetLastError());
+    hipLaunchKernelGGL(set_thresholds_kernel, dim3(1), dim3(64), 0, s, p, g.thr_dev);
+    HIP_OK(h, hipGraphLaunch(g.exec, s));
+    h->last_B = g.last_B; h->last_T = g.last_T; h->last_stages = g.last_stages; h->last_flags = g.last_flags; h->last_gate_heads = g.last_gate_heads;
+    h->layer_stage = g.layer_stage; h->layer_qkv_stage = g.layer_qkv_stage; h->layer_probe_stage = g.layer_probe_stage;
+    h->layer_xprobe = g.layer_xprobe; h->exit_stage = g.exit_stage;
+    const int rc_post = forward_post(h, s);
+    if (rc_post) return rc_post;
+    return launch_status(h, "ee_graph_launch");
+}
+
+int ee_graph_destroy(ee_handle* h, int32_t graph_id) {
+    if (!h) return 1;
+    if (graph_id < 0 || graph_id >= (int32_t)h->graphs.size()) return fail(h, "ee_graph_destroy: no such graph (%d)", graph_id);
+    ee_handle::GraphRec& g = h->graphs[graph_id];
+    if (g.exec) {
+        (void)hipDeviceSynchronize();
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+    }
     return 0;
 }
 
@@ -1463,8 +1604,7 @@ int ee_clock_stamp(uint64_t* out_dev, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(out_dev, 0, MMEE_CLOCK_STAMP_WORDS * sizeof(uint64_t), s) != hipSuccess) return fail(nullptr, "ee_clock_stamp: memset failed");
     hipLaunchKernelGGL(clock_stamp_kernel, dim3(2048), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(out_dev));
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_clock_stamp: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_clock_stamp");
 }
 
 int ee_last_flops(ee_handle* h, double* gemm_flops, double* attn_flops, void* stream) {
@@ -1539,8 +1679,7 @@ int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const
     if (counts && hipMemsetAsync(counts, 0, sizeof(int) * E1, s) != hipSuccess) return fail(nullptr, "ee_policy_scan: memset failed");
     if (N > 0) launch_policy_scan(logits, E1, N, K, thr_dev, exits, predictions, confidence, counts, s);
     (void)hipFreeAsync(thr_dev, s);
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_policy_scan: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_policy_scan");
 }
 
 int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, int32_t N, const double* thr, int32_t V, double* acc,
@@ -1550,8 +1689,7 @@ int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, i
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_threshold_sweep: no HIP device");
     if (V > 0) launch_threshold_sweep(conf, correct, E1, N, thr, V, acc, mean_exit, exit_hist, reinterpret_cast<hipStream_t>(stream));
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_threshold_sweep: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_threshold_sweep");
 }
 
 int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, int32_t N, int32_t K, double* conf, uint8_t* correct,
@@ -1560,8 +1698,7 @@ int ee_msp_table(const double* logits, const int64_t* references, int32_t E1, in
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_msp_table: no HIP device");
     launch_msp_table(logits, (const long long*)references, E1, N, K, conf, correct, reinterpret_cast<hipStream_t>(stream));
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_msp_table: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_msp_table");
 }
 
 int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, int32_t N, int32_t K, int32_t max_iter,
@@ -1571,8 +1708,7 @@ int ee_temperature_fit(const double* logits, const int64_t* labels, int32_t E1, 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_temperature_fit: no HIP device");
     launch_temperature_fit(logits, (const long long*)labels, E1, N, K, max_iter > 0 ? max_iter : 100, temperature, nll, accuracy,
                            avg_confidence, iterations, reinterpret_cast<hipStream_t>(stream));
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_temperature_fit: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_temperature_fit");
 }
 
 // ---- device-side input feed (N2) ----------------------------------------------------------------------------------------
@@ -1598,8 +1734,7 @@ int ee_preprocess_images(const uint8_t* images, const void* desc, int32_t B, int
     launch_preprocess_images(images, static_cast<const ImageDesc*>(desc), B, R, KMAX, max_h, reinterpret_cast<int2*>(ws + o_b),
                              reinterpret_cast<int*>(ws + o_k), reinterpret_cast<unsigned char*>(ws + o_t),
                              reinterpret_cast<const float*>(ws + o_lut), pixel_values, resized_u8, s);
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_preprocess_images: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_preprocess_images");
 }
 
 size_t ee_preprocess_workspace_bytes(int32_t B, int32_t R, int32_t max_h) {
@@ -1616,8 +1751,7 @@ int ee_collate_pad(const int64_t* ids, const int64_t* boxes, const int64_t* offs
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_collate_pad: no HIP device");
     launch_collate_pad((const long long*)ids, (const long long*)boxes, (const long long*)offsets, B, T, pad_id,
                        (long long*)out_ids, (long long*)out_mask, (long long*)out_bbox, reinterpret_cast<hipStream_t>(stream));
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_collate_pad: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_collate_pad");
 }
 
 // ---- debug / micro-benchmark hooks: run ONE kernel of the path on caller-provided device buffers ------------------------
@@ -1653,8 +1787,7 @@ int ee_debug_gemm(const float* A, const float* W, const float* bias, const float
         launch_gemm_f32(g, epi, AMODE_ROWS, M, prop.multiProcessorCount, reinterpret_cast<hipStream_t>(stream));
         set_gemm_wgs_per_cu(0);
     }
-    if (hipGetLastError() != hipSuccess) return fail(nullptr, "ee_debug_gemm: launch failed");
-    return 0;
+    return launch_status(nullptr, "ee_debug_gemm");
 }
 
 int ee_debug_attn_stamps(uint64_t* out8) {

@@ -106,6 +106,8 @@ __global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
     __shared__ int s_carry_docs, s_carry_rows;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.counts->n_docs;
+    const double thr = a.thr_ptr ? a.thr_ptr[a.exit_index] : a.thr;
+    const double temp = a.temp_ptr ? a.temp_ptr[a.exit_index] : a.temp;
     if (tid == 0) { s_carry_docs = 0; s_carry_rows = 0; }
     unsigned long long sq = 0;
     __syncthreads();
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
             orig = a.doc_orig[i];
             len = a.doc_off[i + 1] - a.doc_off[i];
             const float* z = a.pol_logits + (size_t)i * a.K;
-            const double crit = crit_f64(z, a.K, a.temp, a.criterion);
-            bool leave = a.criterion == 0 ? (crit > a.thr) : (crit < a.thr);   // strict, EE/policy.py:33
+            const double crit = crit_f64(z, a.K, temp, a.criterion);
+            bool leave = a.criterion == 0 ? (crit > thr) : (crit < thr);   // strict, EE/policy.py:33
             if (a.no_exit) leave = false;
             if (a.is_final) leave = true;
             if (a.out_all_logits) {
                 float* o = a.out_all_logits + ((size_t)a.exit_index * a.B + orig) * a.K;
-                for (int k = 0; k < a.K; ++k) o[k] = (float)((double)z[k] / a.temp);
+                for (int k = 0; k < a.K; ++k) o[k] = (float)((double)z[k] / temp);
             }
             if (a.out_all_crit) a.out_all_crit[(size_t)a.exit_index * a.B + orig] = (float)crit;
             if (a.head_logits && a.out_head_logits) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
                     crit_f32(a.head_logits + (size_t)i * a.Kh, a.Kh, a.criterion);
             if (leave) {
                 if (a.out_logits)
-                    for (int k = 0; k < a.K; ++k) a.out_logits[(size_t)orig * a.K + k] = (float)((double)z[k] / a.temp);
+                    for (int k = 0; k < a.K; ++k) a.out_logits[(size_t)orig * a.K + k] = (float)((double)z[k] / temp);
                 a.out_exit[orig] = a.exit_index;
                 if (a.out_conf) a.out_conf[orig] = (float)crit;
             }

@@ -26,14 +26,16 @@ inline int diag_env_int(const char* name, int dflt) {
 // INSTANTIATION -- a function-local table of one atomic per device, keyed by the kernel symbol as a template argument -- so a launch costs
 // one hipGetDevice and one relaxed load (no mutex, no search, no table that can fill up: the diagnostic build multiplies instantiations),
 // and a failed opt-in is neither discarded nor left to surface as a generic launch error: it is recorded with the kernel's name and the
-// byte count, and ee_forward / the stand-alone entry points report it (take_lds_error).
+// byte count, and ee_forward / the stand-alone entry points report it (take_lds_error).  Round 6: the slot is PER THREAD -- a
+// launcher runs on the thread of the entry point that called it, so the failure is reported by THAT call (every entry point that launches
+// drains the slot before it returns: launch_status() in capi.hip), never by an unrelated forward of another handle or thread.
 struct LdsOptInError {
     std::mutex mu;
     int code = 0;
     char what[192] = {0};
 };
 inline LdsOptInError& lds_optin_error() {
-    static LdsOptInError e;
+    static thread_local LdsOptInError e;
     return e;
 }
 // returns the recorded failure (and clears it), or nullptr

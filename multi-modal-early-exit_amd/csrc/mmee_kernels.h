@@ -62,11 +62,19 @@ struct HeadOutArgs {
     float* out;                      // [n_docs][Ko]
 };
 
+// thresholds, then temperatures, of one ee_graph_launch: a kernel ARGUMENT of set_thresholds_kernel (no host buffer has to outlive the call)
+struct ThrPack {
+    double v[2 * (64 + 4)];          // 2 x (MMEE_MAX_ENCODER_EXITS + 3 embedding exits + final)
+    int n;
+};
+
 struct DecideArgs {
     const float* pol_logits;         // [n_docs][K]   logits the policy sees (ramp: head logits; gate: classifier(gate input))
     const float* head_logits;        // [n_docs][Kh]  raw exit-head logits (== pol_logits for ramps); null for the final stage
     int K, Kh;
     double thr, temp;
+    const double* thr_ptr;           // captured-graph forwards (ee_graph_capture): threshold / temperature of exit e at [exit_index] of device
+    const double* temp_ptr;          // vectors refreshed in front of every replay; null: the by-value arguments above
     int criterion, is_final, no_exit, exit_index, B;
     // current stage
     const StageCounts* counts;

@@ -4,7 +4,7 @@ Every document is independent in the forward pass and in the policy (EE/policy.p
 and temperatures are precomputed inputs), so the path shards with NO data-path collective: one process per GPU, each
 owning a round-robin slice of the documents (interleaved so that expected exit depth is balanced across ranks), the
 weights replicated.  The single collective is one all-gather of the per-document results
-``[logits (K) f32 | exit_layer i32 (bit pattern) | confidence f32]`` = 4 (K + 2) bytes per document at the end (RCCL over xGMI on GPUs: backend "nccl"; "gloo" in CPU tests).
+``[logits (K) f32 | exit_layer i32 | confidence f32]`` (carried as int32 words) = 4 (K + 2) bytes per document at the end (RCCL over xGMI on GPUs: backend "nccl"; "gloo" in CPU tests).
 The reference has no counterpart (its ``--data-parallel`` flag, EE/configs.py:116-121, is never read).
 """
 from __future__ import annotations
@@ -26,18 +26,23 @@ def shard_size(n_docs: int, rank: int, world: int) -> int:
 
 
 def pack_results(logits, exit_layer, confidence):
-    """(n, K) float32, (n,) int32, (n,) float32 -> (n, K+2) rows of 4-byte words for the ONE all-gather of the north star.  Column K carries
-    the exit index as its int32 BIT PATTERN (a view, not a conversion): the gathered contract is (f32 logits, i32 exit_layer, f32
-    confidence), which ``unpack_results`` returns with those dtypes.  Collectives, ``torch.cat`` and copies move the words untouched; do not
-    do float arithmetic on column K (rounds 1-4 stored the index as a float value -- exact, but not the stated contract)."""
-    ex_bits = exit_layer.to(torch.int32).contiguous().view(torch.float32)
-    return torch.cat([logits.float(), ex_bits.unsqueeze(1), confidence.float().unsqueeze(1)], dim=1)
+    """(n, K) float32, (n,) int32, (n,) float32 -> (n, K+2) rows of 4-byte words for the ONE all-gather of the north star.  The transport
+    dtype of the whole row is INT32 (round 6): logits and confidence travel as their float32 bit patterns (views, not
+    conversions), the exit index as the int32 it is.  Integer copies, concatenations and collectives are never flushed, canonicalised or
+    rounded (round 5 carried the index as a float32 bit pattern, where small indices are denormals and negative ones NaN payloads that any
+    float arithmetic would have destroyed), and float arithmetic on a packed row is now a visible dtype mistake.  The gathered contract is
+    (f32 logits, i32 exit_layer, f32 confidence), which ``unpack_results`` returns with those dtypes."""
+    lg = logits.to(torch.float32).contiguous().view(torch.int32)
+    cf = confidence.to(torch.float32).contiguous().view(torch.int32)
+    return torch.cat([lg, exit_layer.to(torch.int32).unsqueeze(1), cf.unsqueeze(1)], dim=1)
 
 
 def unpack_results(rows):
-    """(n, K+2) packed rows -> (logits float32 (n,K), exit_layer int32 (n,), confidence float32 (n,))."""
+    """(n, K+2) packed int32 rows -> (logits float32 (n,K), exit_layer int32 (n,), confidence float32 (n,))."""
+    if rows.dtype != torch.int32:
+        raise TypeError(f"packed result rows are int32 words (pack_results), got {rows.dtype}")
     K = rows.shape[1] - 2
-    return rows[:, :K], rows[:, K].contiguous().view(torch.int32), rows[:, K + 1]
+    return rows[:, :K].contiguous().view(torch.float32), rows[:, K].contiguous(), rows[:, K + 1].contiguous().view(torch.float32)
 
 
 def _collective_device(t, group=None):

@@ -190,7 +190,7 @@ class EarlyExitEngine:
                 want_all: bool = False, want_head: bool = False, want_hidden_cls: bool = False,
                 validate: bool = False, whole_layers: bool = False, probe_always: bool = False, xprobe: Optional[bool] = None,
                 one_term: bool = False, inputs_embeds=None, want_hidden_states: bool = False, out=None, head_mask=None,
-                want_attentions: bool = False) -> EngineOutput:
+                want_attentions: bool = False, _capture: bool = False) -> EngineOutput:
         """``out``: optional preallocated ``(logits (B,K) f32, exit_layer (B,) i32, confidence (B,) f32)`` device tensors (contiguous; row
         slices of larger tensors qualify) the kernels write into instead of fresh allocations -- MicroBatchedEngine hands each half its slice."""
         if not self._finalized:
@@ -306,6 +306,24 @@ class EarlyExitEngine:
         # tolerance, not bit-identical to whole layers
         # whole_layers / probe_always override the handle's schedule for this call (default: every decision layer probed first, or the mask pin_schedule() set)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if _capture:
+            # ee_graph_capture: the same call eagerly (the outputs hold its results), then its launch list as a hipGraph bound to THESE tensors
+            if emb is not None or hs is not None or hm is not None or att is not None or validate:
+                raise ValueError("capture(): inputs_embeds / hidden states / head_mask / attention maps / validate belong to eager calls")
+            gid = C.c_int32(-1)
+            with torch.cuda.device(dev):
+                cur = torch.cuda.current_stream()
+                if getattr(self, "_cap_stream", None) is None:
+                    self._cap_stream = torch.cuda.Stream(device=dev)      # the legacy null stream (torch's default) cannot be captured
+                self._cap_stream.wait_stream(cur)
+                rc = self.lib.ee_graph_capture(self._h, p(ids), p(am), p(bb), p(px), p(tt), p(ps), B, T, thr_c, tmp_c, flags,
+                                               p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
+                                               p(head_logits), p(head_crit), p(hidden), C.c_void_p(self._cap_stream.cuda_stream), C.byref(gid))
+                capi.check(rc, self._h, "ee_graph_capture")
+                cur.wait_stream(self._cap_stream)
+            res = EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, None, None)
+            ins = dict(input_ids=ids, attention_mask=am, bbox=bb, pixel_values=px, token_type_ids=tt, position_ids=ps)
+            return CapturedForward(self, gid.value, {k: v for k, v in ins.items() if v is not None}, res)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             if not self.beit and emb is not None:
@@ -326,6 +344,16 @@ class EarlyExitEngine:
         return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, hs, att)
 
     __call__ = forward
+
+    def capture(self, *args, **kw) -> "CapturedForward":
+        """The forward as a captured launch list (ee_graph_capture; round 6): same arguments as ``forward``.  The call runs once eagerly --
+        the returned object's ``outputs`` hold its results -- and its launch list is instantiated as a hipGraph bound to the device tensors
+        of THIS call: ``captured.inputs`` are static buffers (``captured.inputs["input_ids"].copy_(next_batch)``), ``captured.outputs`` are
+        rewritten by every ``captured.launch(thresholds=..., temperatures=...)``.  Thresholds and temperatures are arguments of the launch,
+        everything else ((B, T), flags, which optional outputs exist, the pinned exit-layer schedule) is part of the capture.  For the
+        reference's operating point (eval_batch_size = 1, EE/configs.py:36; EE/utils.py:169-193): ~185 kernel launches per forward become
+        one graph launch.  Replays return the bits of the eager call on the same inputs."""
+        return self.forward(*args, _capture=True, **kw)
 
     def check(self):
         """Synchronise and raise ``MMEEError`` if the last forward flagged out-of-range inputs or a split-precision overflow
@@ -437,6 +465,43 @@ class EarlyExitEngine:
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             capi.check(self.lib.ee_last_layer_plan(self._h, q, m, p, L, C.byref(pf), stream), self._h, "ee_last_layer_plan")
         return {"rows_qkv": list(q), "rows_main": list(m), "docs_probe": list(p), "probe_flops": pf.value}
+
+
+class CapturedForward:
+    """One captured configuration of ``EarlyExitEngine.forward`` (see ``EarlyExitEngine.capture``)."""
+
+    def __init__(self, engine: EarlyExitEngine, graph_id: int, inputs: Dict[str, "torch.Tensor"], outputs: EngineOutput):
+        self.engine, self.graph_id, self.inputs, self.outputs = engine, graph_id, inputs, outputs
+
+    def launch(self, thresholds: Optional[Union[float, Sequence[float]]] = None, temperatures: Optional[Sequence[float]] = None,
+               validate: bool = False) -> EngineOutput:
+        """Replay on torch's current stream with this launch's thresholds / temperatures; returns ``self.outputs`` (the same tensors every
+        time: copy what must outlive the next launch)."""
+        eng = self.engine
+        E = eng.E
+        if thresholds is None:
+            thresholds = eng.exit_config.global_threshold
+        thr = np.broadcast_to(np.asarray(thresholds, dtype=np.float64).reshape(-1), (E + 1,)) if np.ndim(thresholds) else np.full((E + 1,), float(thresholds))
+        thr_c = (C.c_double * (E + 1))(*thr.tolist())
+        tmp_c = None
+        if temperatures is not None:
+            tm = np.asarray(temperatures, dtype=np.float64).reshape(-1)
+            if tm.shape[0] != E + 1:
+                raise ValueError(f"temperatures must have {E + 1} entries")
+            tmp_c = (C.c_double * (E + 1))(*tm.tolist())
+        with torch.cuda.device(eng.device):
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            capi.check(eng.lib.ee_graph_launch(eng._h, self.graph_id, thr_c, tmp_c, stream), eng._h, "ee_graph_launch")
+        if validate:
+            eng.stage_counts()
+        return self.outputs
+
+    __call__ = launch
+
+    def close(self):
+        if self.graph_id >= 0 and getattr(self.engine, "_h", None) is not None and self.engine._h.value:
+            self.engine.lib.ee_graph_destroy(self.engine._h, self.graph_id)
+        self.graph_id = -1
 
 
 def load_checkpoint_tensors(path: str) -> Dict[str, "torch.Tensor"]:

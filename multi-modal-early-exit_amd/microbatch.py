@@ -40,6 +40,7 @@ class MicroBatchedEngine:
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n)]
         self._sizes: List[int] = []
+        self._ran = [False] * self.n          # handles that have run a forward (check() visits every one of them, not only the last call's)
 
     # ---- lifetime / parameters -------------------------------------------------------------------------------------------
     def close(self):
@@ -56,6 +57,8 @@ class MicroBatchedEngine:
     # ---- the hot path ---------------------------------------------------------------------------------------------------
     def split_sizes(self, B: int) -> List[int]:
         """Contiguous slices, as even as possible, never more than a handle holds; empty slices are dropped."""
+        if B < 1:
+            raise ValueError(f"B={B}: a forward needs at least one document")
         n = min(self.n, B)
         base, extra = divmod(B, n)
         return [base + (1 if i < extra else 0) for i in range(n)]
@@ -74,6 +77,9 @@ class MicroBatchedEngine:
             raise ValueError("want_hidden_states / out are per-handle features: use EarlyExitEngine")
         sizes = self.split_sizes(B)
         self._sizes = sizes
+        # validate synchronises (ee_last_stage_counts): done once, AFTER every slice has been enqueued and joined -- inside the loop it would
+        # run the slices one after the other
+        validate = bool(kw.pop("validate", False))
         dev = self.device
         e0 = self.engines[0]
         to_dev = lambda x, dt, nm: None if x is None else e0._dev(x, dt, nm)
@@ -110,7 +116,10 @@ class MicroBatchedEngine:
                 for t in (parts[-1].all_logits, parts[-1].all_crit, parts[-1].head_logits, parts[-1].head_crit, parts[-1].hidden_cls, parts[-1].attentions):
                     if t is not None:
                         t.record_stream(cur)
+            self._ran[i] = True
             lo += n
+        if validate:
+            self.check()
         cat = lambda xs, d: None if xs[0] is None else (xs[0] if len(xs) == 1 else torch.cat(xs, dim=d))
         return EngineOutput(out_logits, out_exit, out_conf, cat([p.all_logits for p in parts], 1), cat([p.all_crit for p in parts], 1),
                             cat([p.head_logits for p in parts], 1), cat([p.head_crit for p in parts], 1),
@@ -123,8 +132,11 @@ class MicroBatchedEngine:
         return self.engines[:len(self._sizes)] if self._sizes else self.engines[:1]
 
     def check(self):
-        for e in self._active():
-            e.check()
+        """Synchronise and raise for EVERY handle that has run a forward: a pending device error of a slice that the last (smaller) call did
+        not use is reported too."""
+        for e, ran in zip(self.engines, self._ran):
+            if ran:
+                e.check()
 
     def stage_counts(self):
         cs = [e.stage_counts() for e in self._active()]

@@ -152,20 +152,27 @@ class LayoutLMv3EEForSequenceClassification:
 
     def exit_criterion(self, logits):
         """``max_confidence`` / ``entropy`` on a logits tensor (EE/models/EE_modules.py:149-160)."""
+        self._sync_exit_config()
         if str(self.model_config.exit_config.inference_strategy) == "max_confidence":
             return torch.softmax(logits, dim=1).max(dim=1)[0]
         e = torch.exp(logits)
         return torch.log(e.sum(1)) - (logits * e).sum(1) / e.sum(1)
 
     def _sync_exit_config(self):
-        """``load_assets`` writes ``model.config.exit_config["inference_strategy"]`` (and ``["global_threshold"]``) AFTER the model has been
-        built (EE/utils.py:62-78).  The handle was created with the checkpoint's criterion, so the dictionary is re-read at every call and a
-        changed criterion is pushed down (ee_set_criterion); ``early_exit`` reads the threshold from the same dictionary.  A strategy the
-        kernels do not implement (patience / lte) raises, as ``EarlyExitInference.get_sign`` does in the reference."""
+        """A deliberate EXTENSION of the reference, not its behaviour: the reference binds ``exit_criterion`` / ``threshold_sign`` once in
+        ``__init__`` (EE/models/LayoutLMv3.py:125-131, 342-348), so ``load_assets``' later write of
+        ``model.config.exit_config["inference_strategy"]`` (EE/utils.py:62-78) never reaches its forward -- results agree there only because
+        ``build_model`` merges the CLI configuration into ``EE_config`` BEFORE construction (EE/configs.py:389-393).  Here the dictionary is
+        re-read at every call: a changed criterion is pushed down to the kernels (ee_set_criterion) AND into ``model_config.EE_config``, so that
+        ``exit_criterion()``, ``to_hf_dict()`` and the handle agree; ``early_exit`` reads the threshold from the same dictionary.  A strategy
+        the kernels do not implement (patience / lte) raises, as ``EarlyExitInference.get_sign`` does in the reference."""
         want = self.config.exit_config["inference_strategy"]
         want = str(getattr(want, "value", want))
         if want != str(self.engine.exit_config.inference_strategy):
             self.engine.set_criterion(want)
+        if str(self.model_config.EE_config.get("inference_strategy")) != want:
+            self.model_config.EE_config["inference_strategy"] = want
+            self.config.EE_config["inference_strategy"] = want
 
     # ---- chunked engine call -------------------------------------------------------------------------------------------
     def _run(self, tensors: Dict[str, Any], **kw) -> EngineOutput:
@@ -233,7 +240,12 @@ class LayoutLMv3EEForSequenceClassification:
                                          exit_losses=exit_losses, exit_criteria=exit_criteria, exit_states=exit_states,
                                          gated_logits=gated)
         if return_dict is False:
-            return res.to_tuple()
+            # EE/models/LayoutLMv3.py:883-885: `(logits,) + outputs[1:]`, the loss in front when labels were passed, where `outputs` is the
+            # backbone's own tuple `(sequence_output, [all_hidden_states], [all_attentions])` (:287-296, 654-655) -- the exit fields exist
+            # in the dictionary form only.  (With embedding-level exits or gates the reference's tuple path raises AttributeError at
+            # :648-651, `encoder_outputs.exit_states` on a tuple; the same tuple is returned here for every configuration.)
+            output = (logits,) + tuple(v for v in (hidden_states, attentions) if v is not None)
+            return ((loss,) + output) if loss is not None else output
         return res
 
 
@@ -259,7 +271,13 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
     The reference's "dit" branch loads a stock ``AutoModelForImageClassification`` (EE/configs.py:429-449) and defines no exit
     heads for it; heads here are ``LayoutLMv3Exit`` (EE/models/LayoutLMv3.py:56-93) on the CLS row after each exit layer
     (``beit.encoder.early_exits.k``) — a documented extrapolation.  ``forward(pixel_values, labels=None)`` returns
-    the same ``EESequenceClassifierOutput`` fields; ``early_exit(pixel_values=...)`` is the fast path."""
+    the same ``EESequenceClassifierOutput`` fields; ``early_exit(pixel_values=...)`` is the fast path.
+
+    What this wrapper refuses: ``head_mask`` and ``output_attentions`` (``NotImplementedError``: the side kernels of
+    csrc/attention_maps.hip are built for the LayoutLMv3 layers, whose bias tables they read; BEiT relative-position bias is not
+    built either), a call without ``pixel_values`` (``ValueError``), and every text argument of the LayoutLMv3 signature (there is no
+    text stream).  ``output_hidden_states`` and ``micro_batches`` work as in the base class (hidden states are a per-handle feature and
+    run on the first handle, a slice at a time)."""
 
     def forward(self, pixel_values=None, labels=None, head_mask=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, **kwargs) -> EESequenceClassifierOutput:
@@ -267,25 +285,11 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
             raise ValueError("pixel_values is required")
         if head_mask is not None or output_attentions:
             raise NotImplementedError("head_mask / attention maps are not part of the evaluation hot path")
-        out = self._run(dict(input_ids=None, pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True, validate=True,
+        out = self._run(dict(pixel_values=pixel_values), dump_all=True, want_all=True, want_head=True, validate=True,
                         want_hidden_states=bool(output_hidden_states))      # BeitEncoder: embedding output + every layer's output, (B, Pv, H)
         return self._pack(out, labels, return_dict)
 
     __call__ = forward
-
-    def _run(self, tensors, **kw):
-        self._sync_exit_config()
-        px = tensors["pixel_values"]
-        B, mb = px.shape[0], self.engine.max_docs
-        if B <= mb:
-            return self.engine.forward(pixel_values=px, **kw)
-        parts = [self.engine.forward(pixel_values=px[s:s + mb], **kw) for s in range(0, B, mb)]
-        cat = lambda xs, d: None if xs[0] is None else torch.cat(xs, dim=d)
-        return EngineOutput(cat([p.logits for p in parts], 0), cat([p.exit_layer for p in parts], 0),
-                            cat([p.confidence for p in parts], 0), cat([p.all_logits for p in parts], 1),
-                            cat([p.all_crit for p in parts], 1), cat([p.head_logits for p in parts], 1),
-                            cat([p.head_crit for p in parts], 1), cat([p.hidden_cls for p in parts], 1),
-                            cat([p.hidden_states for p in parts], 1))
 
     def early_exit(self, pixel_values=None, thresholds=None, temperatures=None, **kw) -> EngineOutput:
         if thresholds is None:

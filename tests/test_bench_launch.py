@@ -55,16 +55,19 @@ def test_missing_gpus_fail_loudly_with_a_json_error_line():
     assert "error" in d and "64" in d["error"] and d["value"] is None and d["n_gpus"] == 64 and d["visible_gpus"] < 64
 
 
-def _stub_expectation(n_gpus, batch, n_job, steps_weak=None):
-    """What the stub engine must produce for the job: document g of the job is position (g // world) % batch of rank g % world's resident
-    batch; exit = sum(input_ids) % 6, logits one-hot at sum % 16, confidence 0.5 (bench._StubEngine)."""
+def _stub_expectation(n_gpus, batch, n_job, n_batches):
+    """What the stub engine must produce for the job: document g of the job belongs to rank g % world, is that rank's local document
+    j = g // world, i.e. position j % batch of step j // batch, which runs resident batch (j // batch) % n_batches (round 6: the steps cycle
+    through DISTINCT batches, batch i of rank r drawn with seed 1234 + 1000 r + 7919 i); exit = sum(input_ids) % 6, logits one-hot at
+    sum % 16, confidence 0.5 (bench._StubEngine)."""
     import importlib
     import numpy as np
     pkg = importlib.import_module("multi-modal-early-exit_amd")
     cfg = pkg.ModelConfig.base(EE_config=dict(exits=[2, 4, 6, 8, 10], encoder_layer_strategy="ramp"))
-    sums = [pkg.synth.make_documents(cfg, batch, seed=1234 + 1000 * r, text_len=512)["input_ids"].sum(1) for r in range(n_gpus)]
-    ex = np.array([int(sums[g % n_gpus][(g // n_gpus) % batch] % 6) for g in range(n_job)])
-    hot = np.array([int(sums[g % n_gpus][(g // n_gpus) % batch] % 16) for g in range(n_job)])
+    sums = [[pkg.synth.make_documents(cfg, batch, seed=1234 + 1000 * r + 7919 * i, text_len=512)["input_ids"].sum(1) for i in range(n_batches)]
+            for r in range(n_gpus)]
+    pick = lambda g: sums[g % n_gpus][((g // n_gpus) // batch) % n_batches][(g // n_gpus) % batch]
+    ex = np.array([int(pick(g) % 6) for g in range(n_job)])
     checksum = float(n_job * 1.0 + ex.sum() + 0.5 * n_job)          # one-hot logits + exit index + confidence
     layer = np.array([2, 4, 6, 8, 10, 12])[ex]
     return ex, layer, checksum
@@ -83,7 +86,7 @@ def test_rank_body_weak_scaling_on_two_gloo_ranks():
     """bench.py's own rank body (threshold broadcast -> pinned plan broadcast -> sharded steps -> ONE all-gather -> max over ranks ->
     per-rank statistics -> line) executed by two real ranks over gloo with a stand-in engine: what the driver's N > 1 runs execute, minus the GPU."""
     d = _run_stub(["--steps", "3", "--warmup", "1"])
-    ex, layer, checksum = _stub_expectation(2, 8, 2 * 8 * 3)
+    ex, layer, checksum = _stub_expectation(2, 8, 2 * 8 * 3, 3)        # one resident batch per step
     assert d["stub_engine"] and d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and d["collective_backend"] == "gloo"
     assert d["scaling"] == "weak" and d["steps"] == 3 and d["config"]["total_docs"] == 48
     assert abs(d["gathered_checksum"] - checksum) < 1e-6
@@ -91,13 +94,14 @@ def test_rank_body_weak_scaling_on_two_gloo_ranks():
     assert d["per_rank"]["docs"] == [24, 24]
     assert abs(d["per_rank"]["mean_exit_layer"][0] - layer[0::2].mean()) < 1e-3 and abs(d["per_rank"]["mean_exit_layer"][1] - layer[1::2].mean()) < 1e-3
     assert d["value"] > 0 and len(d["per_rank"]["compute_ms"]) == 2
+    assert d["distinct_documents"]["resident_batches"] == 3 and d["distinct_documents"]["every_timed_document_distinct"]
 
 
 def test_rank_body_strong_scaling_uneven_shards():
     """--total-docs (BASELINE configs[3]'s mode): 37 documents over 2 ranks = shards of 19 and 18, batches of 8 -> 3 steps with a partial
     last batch; the gathered array must hold every document once, in order."""
     d = _run_stub(["--warmup", "0", "--total-docs", "37"])
-    ex, layer, checksum = _stub_expectation(2, 8, 37)
+    ex, layer, checksum = _stub_expectation(2, 8, 37, 3)                # ceil(37 / (2 x 8)) = 3 resident batches
     assert d["scaling"] == "strong" and d["steps"] == 3 and d["config"]["total_docs"] == 37
     assert d["per_rank"]["docs"] == [19, 18]
     assert abs(d["gathered_checksum"] - checksum) < 1e-6
