@@ -390,6 +390,16 @@ def small_batch_block(pkg, a, cfg, W, ee, batch0, B, T, thr, temps, dev, beit):
             sync()
             dt_p = time.perf_counter() - t0
             ex_e = torch.cat([o.exit_layer for o in outs]).cpu().numpy()
+            # whole layers (what the reference does, and what the cost model picks when nobody can be saved much): 7 launches per layer
+            # instead of a 13-launch probe in front of every decision
+            fww = lambda j: eng.forward(*sl(j, n), thresholds=thr_, temperatures=temps_, whole_layers=True)
+            fww(0); sync()
+            wl = []
+            for j in range(min(n_fw, 40)):
+                t0 = time.perf_counter()
+                fww(j)
+                sync()
+                wl.append(time.perf_counter() - t0)
             lat = []
             for j in range(min(n_fw, 40)):
                 t0 = time.perf_counter()
@@ -426,7 +436,8 @@ def small_batch_block(pkg, a, cfg, W, ee, batch0, B, T, thr, temps, dev, beit):
             cap.close()
             res[str(n)] = {"forwards": n_fw,
                            "eager": {"docs_per_sec": n * n_fw / dt_p, "ms_per_forward_pipelined": 1e3 * dt_p / n_fw,
-                                     "ms_per_forward_latency_median": 1e3 * float(np.median(lat))},
+                                     "ms_per_forward_latency_median": 1e3 * float(np.median(lat)),
+                                     "ms_per_forward_latency_median_whole_layers": 1e3 * float(np.median(wl))},
                            "graph": {"docs_per_sec": n * n_fw / dt_g, "ms_per_forward_pipelined": 1e3 * dt_g / n_fw,
                                      "ms_per_forward_latency_median": 1e3 * float(np.median(glat))},
                            "graph_over_eager": (dt_p / dt_g), "exit_indices_equal": bool(np.array_equal(ex_e, ex_g))}
@@ -898,7 +909,8 @@ def main(argv=None):
             "layernorm": sum(2 * r for r in rows) * (H * 4.0 + H * 4.0),                                  # f32 sum in, split planes out
             "embed_text": (B * T if pooled else n_text) * (3 * H * 4.0 + H * 4.0),                       # word + position + 6 spatial slices in, row out
             "embed_visual": B * Pv * (H * 4.0 + H * 4.0) + Pv * H * 4.0,                                  # projected patch in, row out; pos_embed once
-            "pair_index": len_sq * 4.0,                                                                   # one word per (query, key) pair
+            # round 6: two bytes (4 bx, 4 by) per (query, key) pair + the 32-bit words of query block 0 for the X-space probe (T <= 512); before: one word per pair
+            "pair_index": (len_sq * 2.0 + 128.0 * float(lens.sum())) if (not beit and T <= 512) else len_sq * 4.0,
             "patch_split": B * cfg.num_channels * cfg.input_size ** 2 * 8.0,                              # pixel in, split pixel out
             "head_out": sum(docs_e) * (H * 4.0 + K * 4.0) + n_exits * K * H * 4.0,
             "exit_decide": sum(docs_e) * (K * 4.0 + 72.0),

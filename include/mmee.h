@@ -257,6 +257,18 @@ int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const
                    int32_t* exits, double* predictions, double* confidence, int32_t* counts, void* stream);
 
 /*
+ * The row of the north star's ONE all-gather, for hosts that call RCCL themselves (the Python host does the same with tensor views, dist.py):
+ * per document K + 2 int32 words = [logits (K) as their float32 bit patterns | exit_layer | confidence bit pattern].  ee_pack_results builds
+ * rows (dev int32 (n, K+2)) from the three ee_forward outputs; after `ncclAllGather(rows, all_rows, n * (K + 2), ncclInt32, comm, stream)`
+ * (shards padded to one size, rank r's local row i = document r + i * world) ee_unpack_results splits rows back (any output may be NULL).
+ * Integer words are never flushed, canonicalised or rounded on the way.
+ */
+int ee_pack_results(const float* logits, const int32_t* exit_layer, const float* confidence, int32_t n, int32_t K,
+                    int32_t* rows, void* stream);
+int ee_unpack_results(const int32_t* rows, int32_t n, int32_t K, float* logits, int32_t* exit_layer, float* confidence,
+                      void* stream);
+
+/*
  * Many threshold vectors at once over a confidence table (EE/thresh.py:184-215 / EE/large_scale.py:42-84 semantics:
  * exit(v,n) = argmax_e(conf[e,n] >= thr[v,e]) = first exit whose confidence reaches its threshold, 0 when none does;
  * accuracy = mean(correct[exit(v,n), n]), average exit = mean(exit(v,n)), EE/large_scale.py:87-96).

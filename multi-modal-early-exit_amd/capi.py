@@ -81,6 +81,8 @@ SYMBOLS = {
     "ee_set_head_mask": (C.c_int, [_vp, _vp]),
     "ee_set_attentions_out": (C.c_int, [_vp, _vp]),
     "ee_policy_scan": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(C.c_double), _vp, _vp, _vp, _vp, _vp]),
+    "ee_pack_results": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "ee_unpack_results": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ee_threshold_sweep": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ee_msp_table": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ee_debug_gemm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -44,9 +44,24 @@ constexpr int OFF_TX = OFF_TAB + 272;
 constexpr int OFF_TY = OFF_TAB + 528;
 constexpr int OFF_QSLOT = OFF_TAB + 784;
 constexpr int LDS_BYTES = OFF_TAB + 1024;
+// IDX16 (round 6): the head's 1-D bias over DELTA = pos_k - pos_q, index delta + c1, behind the bucket tables (up to 1024 entries: T <= 512)
+// (its own packing: the LDS of a gfx950 workgroup is allocated in granules of 1280 bytes -- 128 per CU -- so three workgroups fit only up to 42
+//  granules = 53760 bytes each; the first build used 54272 and ran TWO workgroups per CU: 11.7 ms against 9.4 ms per forward)
+constexpr int OFF_TX16 = OFF_TAB;             // 64 floats
+constexpr int OFF_TY16 = OFF_TAB + 256;       // 64 floats
+constexpr int OFF_T1V = OFF_TAB + 512;        // T1V_MAX floats
+constexpr int T1V_MAX = 1023;                 // 2 * 512 - 1
+constexpr int OFF_QSLOT16 = OFF_T1V + 4 * T1V_MAX;
+constexpr int LDS_BYTES16 = OFF_QSLOT16 + 4;
+#ifndef MMEE_LKG
+#define MMEE_LKG 8
+#endif
+constexpr int LKG = MMEE_LKG ? MMEE_LKG : 8;                 // scores whose three lookups are issued before the first add of the group (IDX16 fast path)
 constexpr int WGS = 3;
 static_assert(OFF_T1 + 4 * (BINS_MAX + 1) <= OFF_TX && OFF_TX + 4 * BINS_MAX <= OFF_TY && OFF_TY + 4 * BINS_MAX <= OFF_QSLOT, "tables");
 static_assert(WGS * LDS_BYTES <= 160 * 1024 && OFF_TY + 4 * BINS_MAX < 65536, "LDS budget / 16-bit instruction offsets");
+static_assert(WGS * ((LDS_BYTES16 + 1279) / 1280) <= 128 && WGS * ((LDS_BYTES + 1279) / 1280) <= 128 && OFF_T1V + 4 * 31 < 65536,
+              "LDS budget in 1280-byte granules (three workgroups per CU) / 16-bit instruction offsets");
 constexpr float kNegBig = -1.0e30f;
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kPShift = 10.0f;              // probabilities carry 2^10 into the split planes
@@ -143,6 +158,112 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Round 6, the 16-bit pair index (IDX16).  The 1-D bucket of a pair depends on pos_k - pos_q alone, and since the kept text rows of a document
+// are a prefix of its tokens (prep_embed.hip) row j of a document IS token j (visual row j: patch j - n_text): inside a key tile the
+// positions are "tile base + key offset", so the attention kernel reads the 1-D bias from a per-head table over DELTA (1023 entries at
+// T = 512) with the key offset as the INSTRUCTION's immediate -- no index bits, no extract, no bank conflict (32 consecutive queries read 32
+// consecutive words).  What is left per pair is (4 bx, 4 by): two bytes, half the index traffic of the 32-bit word (the index loads were
+// 16 % of the kernel's time, round 3).  Masked keys (past the document in its last tile; pad rows under MMEE_FLAG_DENSE_ROWS; holes) are a
+// property of the KEY, not of the pair: one 32-bit mask per (document, key tile) + a per-document "has a masked key inside" flag.
+//   tile (qb, kb) of a document = 1024 pairs x 2 B at halfword ((qb * nb + kb) * 1024); dword [piece p (0, 1)][lane][w (0..3)] holds the pairs of
+//   score registers e = 8 p + 2 w (low half) and e + 1 (high half) of that lane: byte 0 = 4 bx, byte 1 = 4 by.
+// The workgroups of query block 0 also write what the X-space probe reads (xprobe.hip: the buckets of query 0 against every key, 32-bit
+// words of the old format, [nb][1024] per document) and the key masks.
+__global__ __launch_bounds__(256) void pair_index16_kernel(const RowMeta* __restrict__ meta, const int* __restrict__ doc_off, int n_docs, int nb,
+                                                           const unsigned char* __restrict__ lut1, int c1, int n1,
+                                                           const unsigned char* __restrict__ lut2, int c2, int n2, int bins1,
+                                                           unsigned* __restrict__ out16, size_t doc_stride16, unsigned* __restrict__ out_q0,
+                                                           unsigned* __restrict__ keymask, int* __restrict__ doc_flags, int max_len) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int doc = blockIdx.x / nb, qb = blockIdx.x - doc * nb;
+    if (doc >= n_docs) return;
+    const int off = doc_off[doc], len = doc_off[doc + 1] - off;
+    if (qb * 32 >= len) return;
+    RowMeta* mk_s = reinterpret_cast<RowMeta*>(psm);                       // [max_len]
+    unsigned char* l1 = reinterpret_cast<unsigned char*>(psm) + (size_t)max_len * sizeof(RowMeta);
+    unsigned char* l2 = l1 + ((n1 + 15) & ~15);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < len; i += 256) mk_s[i] = meta[off + i];
+    if (qb == 0) for (int i = tid; i < (n1 + 3) / 4; i += 256) reinterpret_cast<unsigned*>(l1)[i] = reinterpret_cast<const unsigned*>(lut1)[i];
+    for (int i = tid; i < (n2 + 3) / 4; i += 256) reinterpret_cast<unsigned*>(l2)[i] = reinterpret_cast<const unsigned*>(lut2)[i];
+    __syncthreads();
+    const int nkb = (len + 31) / 32;
+    // thread -> (piece p, lane, half h): dwords 2 h, 2 h + 1 of the lane's four = score registers e = 8 p + 4 h + (0..3)
+    const int p = tid >> 7, lane = (tid >> 1) & 63, h = tid & 1, l31 = lane & 31, hh = lane >> 5;
+    const int q = qb * 32 + l31;
+    const RowMeta mq = mk_s[q < len ? q : len - 1];
+    unsigned* slab = out16 + (size_t)doc * doc_stride16 + (size_t)qb * nb * 512;      // 512 dwords per tile
+    for (int kb = 0; kb < nkb; ++kb) {
+        unsigned w[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            unsigned v = 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int e = 8 * p + 4 * h + 2 * d + t;
+                int k = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                k = k < len ? k : len - 1;                   // past the document: any value, the key is masked
+                const RowMeta mk = mk_s[k];
+                const unsigned bx = l2[(mk.x0 - mq.x0) / 4 + c2], by = l2[(mk.y1 - mq.y1) / 4 + c2];
+                v |= ((bx << 2) | (by << 10)) << (16 * t);
+            }
+            w[d] = v;
+        }
+        *reinterpret_cast<u32x2*>(slab + (size_t)kb * 512 + p * 256 + lane * 4 + 2 * h) = u32x2{w[0], w[1]};
+    }
+    if (qb != 0) return;
+    // ---- query block 0 only: the old-format words of its tiles (X-space probe) and the key masks ----
+    {
+        const int p4 = tid >> 6, ln = tid & 63, q0 = ln & 31, h0 = ln >> 5;
+        const RowMeta m0 = mk_s[q0 < len ? q0 : len - 1];
+        unsigned* q0slab = out_q0 + (size_t)doc * nb * 1024;
+        for (int kb = 0; kb < nkb; ++kb) {
+            u32x4 w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = 4 * p4 + t;
+                const int k = kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h0;
+                unsigned v;
+                if (k < len) {
+                    const RowMeta mk = mk_s[k];
+                    const unsigned b1 = mk.flags != 0 ? (unsigned)bins1 : (unsigned)l1[(mk.pos - m0.pos) / 4 + c1];
+                    const unsigned bx = l2[(mk.x0 - m0.x0) / 4 + c2], by = l2[(mk.y1 - m0.y1) / 4 + c2];
+                    v = (b1 << 2) | (bx << 12) | (by << 22);
+                } else {
+                    v = (unsigned)bins1 << 2;
+                }
+                w[t] = v;
+            }
+            *reinterpret_cast<u32x4*>(q0slab + (size_t)kb * 1024 + p4 * 256 + ln * 4) = w;
+        }
+        // key masks: bit j of keymask[doc][kb] <-> key 32 kb + j is masked (past the document, or flagged); doc_flags: any flagged key INSIDE
+        bool inside = false;
+        for (int kb = tid >> 6; kb < nkb; kb += 4) {
+            const int k = kb * 32 + (ln & 31);
+            const bool fl = k < len && mk_s[k].flags != 0;
+            const bool msk = k >= len || fl;
+            const unsigned long long bal = __ballot(msk);
+            inside |= __any(fl);
+            if (ln == 0) keymask[(size_t)doc * nb + kb] = (unsigned)(bal & 0xffffffffull);
+        }
+        __shared__ int s_in;
+        if (tid == 0) s_in = 0;
+        __syncthreads();
+        if (inside && (tid & 63) == 0) atomicOr(&s_in, 1);
+        __syncthreads();
+        if (tid == 0) doc_flags[doc] = s_in;
+    }
+}
+
+void launch_pair_index16(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1, int n1,
+                         const unsigned char* lut2, int c2, int n2, int bins1, unsigned* out16, size_t doc_stride16, unsigned* out_q0,
+                         unsigned* keymask, int* doc_flags, int max_len, hipStream_t s) {
+    const size_t lds = (size_t)max_len * sizeof(RowMeta) + ((n1 + 15) & ~15) + ((n2 + 15) & ~15);
+    hipLaunchKernelGGL(pair_index16_kernel, dim3(n_docs * nb), dim3(256), lds, s, meta, doc_off, n_docs, nb, lut1, c1, n1, lut2, c2, n2, bins1, out16,
+                       doc_stride16, out_q0, keymask, doc_flags, max_len);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // The attention kernel.  MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads;
 // its run time means nothing, the SHARES do); 2 timing variants selected by `dbg` (wrong results).  Modes 1 and 2 exist in the
 // diagnostic library only (-DMMEE_DIAG).  BIAS: relative-position bias from the pair index (LayoutLMv3) or none (image-only).
@@ -202,9 +323,16 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // Removed; the kernel below is the round-4 form.
 constexpr int kXP = 2 | 16;
 // TERMS = 1 (MMEE_FLAG_ONE_TERM, a reported low-precision mode, never a parity path): both products on the hi planes only.
-template <int MODE, bool BIAS, int XP, int TERMS = 3>
+// IDX = 16 (round 6): the 16-bit pair index + the 1-D bias as a DELTA table read at "tile base + immediate" (header of pair_index16_kernel):
+// 32 instead of 48 bit-field extracts, 2 instead of 4 index loads per key tile, 8 instead of 16 index registers, no bank conflict in the 1-D
+// lookups.  A key tile takes the FAST lookups when its 32 keys are 32 consecutive positions and none of them is masked; the tile in which a
+// document's text ends and its visual rows begin, a tile with a masked key (the document's partial last tile; pad rows / holes) take the SLOW
+// form (a per-score select of the table base and of -1e30): one or two of a document's ~15 tiles.
+template <int MODE, bool BIAS, int XP, int TERMS = 3, int IDX = 32>
 __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs a, unsigned long long* __restrict__ stamps, const int dbg) {
     constexpr bool DIAG = MODE == 1;
+    constexpr bool I16 = BIAS && IDX == 16;
+    static_assert(!I16 || (XP & 2), "IDX16 is built on the bias-first form");
     constexpr bool R2 = (XP & 4) != 0;          // experiment: two ring slots in use, tile kt + 1 fetched during tile kt
     constexpr int AHEAD = R2 ? 1 : 2;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -224,7 +352,7 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         return;
     }
 
-    int* q_slot = reinterpret_cast<int*>(smem + OFF_QSLOT);
+    int* q_slot = reinterpret_cast<int*>(smem + ((BIAS && IDX == 16) ? OFF_QSLOT16 : OFF_QSLOT));
     const int my_xcd = a.item_counter ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u) : 0;   // HW_REG_XCC_ID
     int q_try = 0;
     int item = blockIdx.x;
@@ -299,11 +427,18 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         auto fill_tables = [&]() __attribute__((always_inline)) {
             if (BIAS && head != cur_head) {            // the head's raw bucket tables, pre-scaled; entry bins1 of T1 = masked key
                 float* T1 = reinterpret_cast<float*>(smem + OFF_T1);
-                float* TX = reinterpret_cast<float*>(smem + OFF_TX);
-                float* TY = reinterpret_cast<float*>(smem + OFF_TY);
+                float* TX = reinterpret_cast<float*>(smem + (I16 ? OFF_TX16 : OFF_TX));
+                float* TY = reinterpret_cast<float*>(smem + (I16 ? OFF_TY16 : OFF_TY));
                 const float f = a.inv_sqrt_d * sc2;
-                if (tid < a.bins1) T1[tid] = a.w1[(size_t)head * a.bins1 + tid] * f;
-                if (tid == a.bins1) T1[tid] = kNegBig;
+                if (I16) {                             // T1V[delta + c1] = w1[head][bucket_1d(delta)] * f: the same values the bucket table holds
+                    float* T1V = reinterpret_cast<float*>(smem + OFF_T1V);
+                    // a.t1 = w1[head][bucket_1d(delta)] / sqrt(d) (ee_finalize's value tables); x s_q s_k, a power of two: the bits of
+                    // w1[.] * (1 / sqrt(d) * s_q s_k) that the bucket table of the 32-bit form holds, without the LUT gather per head change
+                    for (int i = tid; i < a.n1; i += 256) T1V[i] = a.t1[(size_t)head * a.n1 + i] * sc2;
+                } else {
+                    if (tid < a.bins1) T1[tid] = a.w1[(size_t)head * a.bins1 + tid] * f;
+                    if (tid == a.bins1) T1[tid] = kNegBig;
+                }
                 if (tid >= 64 && tid < 64 + a.bins2) TX[tid - 64] = a.wx[(size_t)head * a.bins2 + tid - 64] * f;
                 if (tid >= 128 && tid < 128 + a.bins2) TY[tid - 128] = a.wy[(size_t)head * a.bins2 + tid - 128] * f;
                 cur_head = head;
@@ -473,9 +608,24 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
         const int n_kt = (len + KT - 1) / KT, n_full = len / KT;
         const bool want_idx = BIAS && !(MODE == 2 && (dbg & (1 | 32)));
         // index words of one key tile: four asm loads from a scalar tile pointer
-        const unsigned* idx_base = BIAS ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * 1024 : nullptr;
+        const unsigned* idx_base = BIAS ? a.pair_idx + (size_t)slab * a.idx_doc_stride + (size_t)qb * a.idx_nb * (I16 ? 512 : 1024) : nullptr;
         u32x4 iw0 = {0u, 0u, 0u, 0u}, iw1 = iw0, iw2 = iw0, iw3 = iw0;
+        // IDX16: row j of a document is token j (j < nt) or patch j - nt; this lane's query position, the byte offset of its delta = 0 entry
+        // minus that position (+ 16 bytes for the upper lane half, whose keys sit 4 further), the tile the text ends in, the document's masks
+        const int nt16 = I16 ? len - a.n_visual : 0;
+        const int qc16 = qi < len ? qi : len - 1;
+        const unsigned abase16 = I16 ? (unsigned)(4 * (a.c1 - (qc16 < nt16 ? qc16 : qc16 - nt16)) + 16 * hh) : 0u;
+        const int kts16 = I16 ? ((nt16 & 31) ? (nt16 >> 5) : -1) : -1;
+        const bool docmask16 = I16 && __builtin_amdgcn_readfirstlane(a.doc_flags[slab]) != 0;      // fetched before the counted regime starts
         auto issue_idx = [&](int kt) __attribute__((always_inline)) {
+            if (I16) {
+                const unsigned long long ib16 = sgpr64((unsigned long long)(size_t)idx_base + (unsigned long long)kt * 2048ull);
+                asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                             : "+v"(iw0), "+v"(iw1)
+                             : "v"(ivoff), "s"(ib16)
+                             : "memory");
+                return;
+            }
             const unsigned long long ib = sgpr64((unsigned long long)(size_t)idx_base + (unsigned long long)kt * 4096ull);
             // s_nop 4: the scalar base may come straight from v_readfirstlane (VALU write of an SGPR -> VMEM read needs 5 wait
             // states, and nothing inside an asm string is padded by the compiler)
@@ -552,7 +702,99 @@ __global__ __launch_bounds__(256, WGS) void attention_idx_kernel(const AttnArgs 
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if (want_idx && BF) lookups(true);            // the bias IS the initial accumulator: the matrix pipe adds it to the scores
+            auto lookups16 = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned iwv[8] = {iw0[0], iw0[1], iw0[2], iw0[3], iw1[0], iw1[1], iw1[2], iw1[3]};
+                const int k0 = kt * KT;
+                // masked keys of this tile: past the document (only its last tile can have them), or flagged rows (pad rows under
+                // MMEE_FLAG_DENSE_ROWS, holes in the mask: per-document flag, then one scalar load per tile -- the slow path of a rare input)
+                unsigned km = 0u;
+                if (VAR == V_LAST && k0 + KT > len) km = ~0u << (unsigned)(len - k0);
+                if (docmask16) {
+                    const unsigned* kmp = a.keymask + (size_t)slab * a.idx_nb + kt;
+                    unsigned kv;
+                    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kv) : "s"(kmp) : "memory");
+                    km |= kv;
+                }
+                const bool straddle = kt == kts16;
+                // byte offset of (position of the tile's first key) in the delta table, seen from this lane's query
+                const unsigned At = abase16 + 4u * (unsigned)(k0 >= nt16 ? k0 - nt16 : k0);
+                if (!straddle && km == 0u) {
+                    // two halves of 8 scores: all 24 reads of a half are ISSUED before its first add (left to itself hipcc waits lgkmcnt(0) behind
+                    // every four reads -- eight LDS round trips per tile instead of two: the first build of this path ran 9.8 ms against 9.2 ms)
+#if MMEE_LKG == 0
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        if (p == 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int e = 4 * p + t, kk0 = (e & 3) + 8 * (e >> 2);
+                            const unsigned w = iwv[e >> 1];
+                            const float b1 = lds_load<float>(At + (unsigned)(OFF_T1V + 4 * kk0));
+                            const float bx = lds_load<float>(((e & 1) ? ((w >> 16) & 0xffu) : (w & 0xffu)) + (unsigned)OFF_TX16);
+                            const float by = lds_load<float>(((e & 1) ? (w >> 24) : ((w >> 8) & 0xffu)) + (unsigned)OFF_TY16);
+                            s[e] = b1 + (bx + by);
+                        }
+                    }
+#else
+#pragma unroll
+                    for (int hf = 0; hf < 16 / LKG; ++hf) {
+                        float b1v[LKG], bxv[LKG], byv[LKG];
+#pragma unroll
+                        for (int i = 0; i < LKG; ++i) {
+                            const int e = LKG * hf + i, kk0 = (e & 3) + 8 * (e >> 2);
+                            const unsigned w = iwv[e >> 1];
+                            b1v[i] = lds_load<float>(At + (unsigned)(OFF_T1V + 4 * kk0));
+                            bxv[i] = lds_load<float>(((e & 1) ? ((w >> 16) & 0xffu) : (w & 0xffu)) + (unsigned)OFF_TX16);
+                            byv[i] = lds_load<float>(((e & 1) ? (w >> 24) : ((w >> 8) & 0xffu)) + (unsigned)OFF_TY16);
+                        }
+                        // an empty asm that names every result: all reads of the group are issued (and have landed) in front of it
+                        static_assert(LKG == 4 || LKG == 8, "LKG");
+                        if (LKG == 8)
+                            asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]), "+v"(b1v[4 % LKG]), "+v"(b1v[5 % LKG]), "+v"(b1v[6 % LKG]), "+v"(b1v[7 % LKG]),
+                                              "+v"(bxv[0]), "+v"(bxv[1]), "+v"(bxv[2]), "+v"(bxv[3]), "+v"(bxv[4 % LKG]), "+v"(bxv[5 % LKG]), "+v"(bxv[6 % LKG]), "+v"(bxv[7 % LKG]),
+                                              "+v"(byv[0]), "+v"(byv[1]), "+v"(byv[2]), "+v"(byv[3]), "+v"(byv[4 % LKG]), "+v"(byv[5 % LKG]), "+v"(byv[6 % LKG]), "+v"(byv[7 % LKG]));
+                        else
+                            asm volatile("" : "+v"(b1v[0]), "+v"(b1v[1]), "+v"(b1v[2]), "+v"(b1v[3]), "+v"(bxv[0]), "+v"(bxv[1]), "+v"(bxv[2]), "+v"(bxv[3]),
+                                              "+v"(byv[0]), "+v"(byv[1]), "+v"(byv[2]), "+v"(byv[3]));
+#pragma unroll
+                        for (int i = 0; i < LKG; ++i) s[LKG * hf + i] = b1v[i] + (bxv[i] + byv[i]);
+                    }
+#endif
+                } else {
+                    // keys >= m of this tile are visual rows: their positions restart at 0
+                    const int m = straddle ? (nt16 & 31) : KT;
+                    const unsigned Av = abase16 - 4u * (unsigned)m;
+                    const int vthr = m - 4 * hh;
+                    const unsigned kml = km >> (4 * hh);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        __builtin_amdgcn_sched_barrier(0);      // four scores at a time: this path is rare, its registers must not set the kernel's budget
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int e = 4 * p + t, kk0 = (e & 3) + 8 * (e >> 2);
+                            // the extracts as asm: were they the fast path's expressions, hipcc would hoist all 32 of them above the branch
+                            // (32 live registers in front of BOTH paths: 168 VGPRs + spills in the first build)
+                            unsigned ox, oy;
+                            asm volatile("v_bfe_u32 %0, %2, %3, 8\n\tv_bfe_u32 %1, %2, %4, 8" : "=&v"(ox), "=&v"(oy) : "v"(iwv[e >> 1]), "n"(16 * (e & 1)), "n"(16 * (e & 1) + 8));
+                            // (the key offset is added BEFORE the read here: Av alone can be negative for a query near the end of the text)
+                            const unsigned Ab = (kk0 >= vthr ? Av : At) + 4u * (unsigned)kk0;
+                            const float b1 = lds_load<float>(Ab + (unsigned)OFF_T1V);
+                            const float bx = lds_load<float>(ox + (unsigned)OFF_TX16);
+                            const float by = lds_load<float>(oy + (unsigned)OFF_TY16);
+                            const float b = b1 + (bx + by);
+                            s[e] = ((kml >> kk0) & 1u) ? kNegBig : b;
+                        }
+                    }
+                }
+                if (more1) {                     // the registers are free: fetch the next tile's words
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_idx(kt + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (want_idx && BF && I16) lookups16();
+            else if (want_idx && BF) lookups(true);       // the bias IS the initial accumulator: the matrix pipe adds it to the scores
             else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -658,15 +900,19 @@ static unsigned long long* g_attn_idx_stamps = nullptr;
 unsigned long long* attention_idx_stamps() { return g_attn_idx_stamps; }
 
 bool attention_idx_supports(const AttnArgs& a) {
+    if (a.idx16 && !(a.pair_idx && a.lut1 && a.keymask && a.doc_flags && a.n1 >= 1 && a.n1 <= T1V_MAX && a.n_visual >= 0)) return false;
     return a.ctx_split && (a.pair_idx == nullptr || (a.bins1 >= 1 && a.bins1 <= BINS_MAX && a.bins2 >= 1 && a.bins2 <= BINS_MAX));
 }
+// can a handle with these bucket tables / this delta range run the 16-bit index?  (capi.hip decides once per handle)
+bool attention_idx16_fits(int bins1, int bins2, int n1) { return bins1 >= 1 && bins1 <= BINS_MAX && bins2 >= 1 && bins2 <= BINS_MAX && n1 >= 1 && n1 <= T1V_MAX; }
 
-template <bool BIAS, int XP, int TERMS = 3>
+template <bool BIAS, int XP, int TERMS = 3, int IDX = 32>
 static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned long long* stamps, int dbg, hipStream_t s) {
-    (void)ensure_dynamic_lds<&attention_idx_kernel<0, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
+    constexpr int LDSB = (BIAS && IDX == 16) ? LDS_BYTES16 : LDS_BYTES;
+    (void)ensure_dynamic_lds<&attention_idx_kernel<0, BIAS, XP, TERMS, IDX>>("attention_idx_kernel", LDSB);
 #ifdef MMEE_DIAG
-    (void)ensure_dynamic_lds<&attention_idx_kernel<1, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
-    (void)ensure_dynamic_lds<&attention_idx_kernel<2, BIAS, XP, TERMS>>("attention_idx_kernel", LDS_BYTES);
+    (void)ensure_dynamic_lds<&attention_idx_kernel<1, BIAS, XP, TERMS, IDX>>("attention_idx_kernel", LDSB);
+    (void)ensure_dynamic_lds<&attention_idx_kernel<2, BIAS, XP, TERMS, IDX>>("attention_idx_kernel", LDSB);
 #endif
     const int qtiles = (a.max_len + QT - 1) / QT;
     long items = (long)max_docs * a.heads * qtiles;
@@ -674,11 +920,11 @@ static void launch_idx(const AttnArgs& a, int max_docs, int num_cus, unsigned lo
     if (items < grid) grid = (int)items;
     if (grid < 1) grid = 1;
 #ifdef MMEE_DIAG      // stamped build and timing variants (wrong results): diagnostic library only
-    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, stamps, 0); return; }
-    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, dbg); return; }
+    if (stamps) { hipLaunchKernelGGL((attention_idx_kernel<1, BIAS, XP, TERMS, IDX>), dim3(grid), dim3(256), LDSB, s, a, stamps, 0); return; }
+    if (dbg) { hipLaunchKernelGGL((attention_idx_kernel<2, BIAS, XP, TERMS, IDX>), dim3(grid), dim3(256), LDSB, s, a, (unsigned long long*)nullptr, dbg); return; }
 #endif
     (void)stamps; (void)dbg;
-    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS, XP, TERMS>), dim3(grid), dim3(256), LDS_BYTES, s, a, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL((attention_idx_kernel<0, BIAS, XP, TERMS, IDX>), dim3(grid), dim3(256), LDSB, s, a, (unsigned long long*)nullptr, 0);
 }
 
 // a.pair_idx == nullptr: no relative-position bias (image-only model); only the tail of a document's last key tile is masked.
@@ -698,7 +944,7 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
     stamps = stamps_buf;
     dbg = dbg_env;
     g_attn_idx_stamps = stamps;
-    if (a.pair_idx && xp != kXP) {
+    if (a.pair_idx && xp != kXP && !a.idx16) {
         switch (xp) {
             case 0: launch_idx<true, 0>(a, max_docs, num_cus, stamps, dbg, s); return;
             case 2: launch_idx<true, 2>(a, max_docs, num_cus, stamps, dbg, s); return;
@@ -711,6 +957,11 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         }
     }
 #endif
+    if (a.pair_idx && a.idx16) {         // round 6: 16-bit pair index + delta table (the default wherever the handle's shapes allow it)
+        if (a.terms == 1 && !stamps && !dbg) launch_idx<true, kXP, 1, 16>(a, max_docs, num_cus, nullptr, 0, s);      // MMEE_FLAG_ONE_TERM
+        else launch_idx<true, kXP, 3, 16>(a, max_docs, num_cus, stamps, dbg, s);
+        return;
+    }
     if (a.terms == 1 && a.pair_idx && !stamps && !dbg) { launch_idx<true, kXP, 1>(a, max_docs, num_cus, nullptr, 0, s); return; }      // MMEE_FLAG_ONE_TERM
     if (a.pair_idx) launch_idx<true, kXP>(a, max_docs, num_cus, stamps, dbg, s);
     else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);      // no bias to put first

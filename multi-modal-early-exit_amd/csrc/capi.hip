@@ -75,7 +75,13 @@ struct ee_handle {
     unsigned* pair_idx = nullptr;                 // split mode, LayoutLMv3: one word per (query, key) pair of every document (attention_idx.hip)
     unsigned char *lut1_dev = nullptr, *lut2_dev = nullptr;
     int idx_nb = 0;
-    size_t idx_stride = 0;
+    size_t idx_stride = 0;                        // dwords per document slab of pair_idx
+    // round 6, 16-bit pair index (attention_idx.hip IDX16): pair_idx holds 2 bytes per pair; the X-space probe reads the 32-bit words of query
+    // block 0 from pair_idx0 ([max_docs][idx_nb][1024]); key masks per (document, key tile), "a key inside the document is masked" per document
+    bool idx16 = false;
+    unsigned* pair_idx0 = nullptr;
+    unsigned* keymask = nullptr;
+    int* doc_flags = nullptr;
     float* cls_f32 = nullptr;                     // split mode: CLS rows of the active documents rebuilt from the split planes
     // CLS probe (probe-first layers): one row per active document
     float *Yc = nullptr, *Ycs = nullptr, *H1c = nullptr, *Xc = nullptr, *Xcs = nullptr;
@@ -545,8 +551,16 @@ int ee_create(const ee_config* c, ee_handle** out) {
             }
             if (!beit) {
                 h->idx_nb = (int)((Tm + Pv + 31) / 32);
-                h->idx_stride = (size_t)h->idx_nb * h->idx_nb * 1024;
+                const int maxpos = (int)std::max(Tm, Pv);
+                static const int idx_env = mmee::diag_env_int("MMEE_ATTN_IDX", 16);      // diagnostic library only: 32 = the round-2..5 word index (A/B)
+                h->idx16 = idx_env == 16 && mmee::attention_idx16_fits(c->rel_pos_bins, c->rel_2d_pos_bins, 2 * maxpos - 1);
+                h->idx_stride = (size_t)h->idx_nb * h->idx_nb * (h->idx16 ? 512 : 1024);
                 rc |= dev_alloc(h, &h->pair_idx, Bm * h->idx_stride);
+                if (h->idx16) {
+                    rc |= dev_alloc(h, &h->pair_idx0, Bm * (size_t)h->idx_nb * 1024);
+                    rc |= dev_alloc(h, &h->keymask, Bm * (size_t)h->idx_nb);
+                    rc |= dev_alloc(h, &h->doc_flags, Bm);
+                }
             }
         }
         rc |= dev_alloc(h, &h->vis_raw, Bm * NP * H);
@@ -920,8 +934,12 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
         launch_prep(pa, s);
         if (h->pair_idx && use_idx) {    // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
             ProfScope pi(h, P_PAIRIDX, s);
-            mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
-                                    h->pair_idx, h->idx_stride, max_len, s);
+            if (h->idx16)
+                mmee::launch_pair_index16(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
+                                          h->pair_idx, h->idx_stride, h->pair_idx0, h->keymask, h->doc_flags, max_len, s);
+            else
+                mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
+                                        h->pair_idx, h->idx_stride, max_len, s);
         }
     }
 
@@ -980,6 +998,7 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
         at.idx_doc_stride = h->idx_stride; at.idx_nb = h->idx_nb; at.doc_orig = S_doc_orig(cur);
         at.w1 = h->rel1; at.wx = h->relx; at.wy = h->rely; at.bins1 = c.rel_pos_bins; at.bins2 = c.rel_2d_pos_bins;
         at.inv_sqrt_d = 1.0f / std::sqrt((float)(H / c.num_attention_heads));
+        at.idx16 = (h->idx16 && at.pair_idx) ? 1 : 0; at.lut1 = h->lut1_dev; at.n_visual = Pv; at.keymask = h->keymask; at.doc_flags = h->doc_flags;
     };
     const int* x_phys = S_x_src(0);
     bool use_row_src = false;
@@ -1261,7 +1280,7 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
                 xa.doc_orig = S_doc_orig(cur); xa.counts = &h->counts[cur]; xa.qc = h->Qc;
                 xa.wk = w.qkv_w + (size_t)H * H; xa.bk = w.qkv_b + H; xa.wv_s = w.qkv_s + (size_t)2 * H * H; xa.wv_inv = w.qkv_inv; xa.bv = w.qkv_b + 2 * H;
                 xa.u = h->xp_u; xa.s0 = h->xp_s0; xa.cvec = h->xp_c; xa.order = h->xp_order; xa.ticket = h->xp_order + B; xa.ctx = h->CTX; xa.ctx_scale = mmee::kSplitScaleCtx;
-                xa.pair_idx = h->pair_idx; xa.idx_doc_stride = h->idx_stride; xa.w1 = h->rel1; xa.wx = h->relx; xa.wy = h->rely;
+                xa.pair_idx = h->idx16 ? h->pair_idx0 : h->pair_idx; xa.idx_doc_stride = h->idx16 ? (size_t)h->idx_nb * 1024 : h->idx_stride; xa.w1 = h->rel1; xa.wx = h->relx; xa.wy = h->rely;
                 xa.bins1 = c.rel_pos_bins; xa.bins2 = c.rel_2d_pos_bins; xa.inv_sqrt_d = 1.0f / std::sqrt((float)(H / c.num_attention_heads));
                 xa.H = H; xa.heads = c.num_attention_heads; xa.err_flag = h->err_flag;
                 mmee::launch_xprobe(xa, B, max_len, cus, s);
@@ -1680,6 +1699,22 @@ int ee_policy_scan(const double* logits, int32_t E1, int32_t N, int32_t K, const
     if (N > 0) launch_policy_scan(logits, E1, N, K, thr_dev, exits, predictions, confidence, counts, s);
     (void)hipFreeAsync(thr_dev, s);
     return launch_status(nullptr, "ee_policy_scan");
+}
+
+int ee_pack_results(const float* logits, const int32_t* exit_layer, const float* confidence, int32_t n, int32_t K, int32_t* rows, void* stream) {
+    if (n < 0 || K < 1 || (n > 0 && (!logits || !exit_layer || !confidence || !rows))) return fail(nullptr, "ee_pack_results: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_pack_results: no HIP device");
+    if (n > 0) launch_pack_results(logits, exit_layer, confidence, n, K, rows, reinterpret_cast<hipStream_t>(stream));
+    return launch_status(nullptr, "ee_pack_results");
+}
+
+int ee_unpack_results(const int32_t* rows, int32_t n, int32_t K, float* logits, int32_t* exit_layer, float* confidence, void* stream) {
+    if (n < 0 || K < 1 || (n > 0 && !rows)) return fail(nullptr, "ee_unpack_results: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, "ee_unpack_results: no HIP device");
+    if (n > 0) launch_unpack_results(rows, n, K, logits, exit_layer, confidence, reinterpret_cast<hipStream_t>(stream));
+    return launch_status(nullptr, "ee_unpack_results");
 }
 
 int ee_threshold_sweep(const double* conf, const uint8_t* correct, int32_t E1, int32_t N, const double* thr, int32_t V, double* acc,

@@ -212,6 +212,42 @@ void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, cons
                        meta_old, meta_new, row_src);
 }
 
+// (logits f32 (n,K), exit_layer i32 (n), confidence f32 (n)) <-> the row of the ONE all-gather of the north star: K + 2 int32 words per document
+// (the floats travel as their bit patterns: integer copies and collectives never flush, canonicalise or round them)
+__global__ __launch_bounds__(256) void pack_results_kernel(const float* __restrict__ logits, const int* __restrict__ exit_layer,
+                                                           const float* __restrict__ conf, int n, int K, int* __restrict__ rows) {
+    const long total = (long)n * (K + 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d = (int)(i / (K + 2)), c = (int)(i - (long)d * (K + 2));
+        rows[i] = c < K ? __float_as_int(logits[(size_t)d * K + c]) : c == K ? exit_layer[d] : __float_as_int(conf[d]);
+    }
+}
+__global__ __launch_bounds__(256) void unpack_results_kernel(const int* __restrict__ rows, int n, int K, float* __restrict__ logits,
+                                                             int* __restrict__ exit_layer, float* __restrict__ conf) {
+    const long total = (long)n * (K + 2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d = (int)(i / (K + 2)), c = (int)(i - (long)d * (K + 2));
+        const int v = rows[i];
+        if (c < K) { if (logits) logits[(size_t)d * K + c] = __int_as_float(v); }
+        else if (c == K) { if (exit_layer) exit_layer[d] = v; }
+        else if (conf) conf[d] = __int_as_float(v);
+    }
+}
+void launch_pack_results(const float* logits, const int* exit_layer, const float* conf, int n, int K, int* rows, hipStream_t s) {
+    long total = (long)n * (K + 2);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(pack_results_kernel, dim3(grid), dim3(256), 0, s, logits, exit_layer, conf, n, K, rows);
+}
+void launch_unpack_results(const int* rows, int n, int K, float* logits, int* exit_layer, float* conf, hipStream_t s) {
+    long total = (long)n * (K + 2);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(unpack_results_kernel, dim3(grid), dim3(256), 0, s, rows, n, K, logits, exit_layer, conf);
+}
+
 // out[orig][:] = X[x_phys[i]][:]   (CLS rows, parity/debug output)
 // CLS row of every active document -> out[doc_orig ? doc_orig[i] : i].  split_inv != 0: X holds split-f16 rows (1 / scale = split_inv)
 __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict__ X, int H, const int* __restrict__ x_phys,

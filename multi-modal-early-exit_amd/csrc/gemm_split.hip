@@ -57,10 +57,24 @@ void launch_gemm_split(const GemmArgs& a_in, int epi, int max_m, int num_cus, hi
         // not a shape the probe launches: the default configuration below computes the same bits
     }
     a.k_splits = 1;      // every kernel below writes ONE part
+    // Round 6, small batches (the reference evaluates at eval_batch_size = 1, EE/configs.py:36; bench.py `small_batch`): a forward of one document is
+    // 709 rows -- 27 of the default 256 x 256 tiles in the Q|K|V projection, 9 in the attention-output GEMM, on 256 CUs.  When the default tiles
+    // would leave more than half of the chip without one, a layer GEMM takes the CLS-probe launches' 128 x 128 / 4-wave configuration (four
+    // times the tiles, static assignment): same MFMA form, k order and term order => the same bits, so nothing observable changes but the time.
+    if (a.terms != 1 && (long)((max_m + 255) / 256) * (a.N / 256) * 2 <= (long)num_cus) {
+        a.tile_counter = nullptr;
+        if (a.out_split && epi == EPI_GELU) { launch_split_one<CfgP, EPI_GELU, true, false, 1>(a, max_m, num_cus, s); return; }
+        if (a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, true, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_RESID) { launch_split_one<CfgP, EPI_RESID, false, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_BIAS) { launch_split_one<CfgP, EPI_BIAS, false, false, 1>(a, max_m, num_cus, s); return; }
+        if (!a.out_split && epi == EPI_TANH) { launch_split_one<CfgP, EPI_TANH, false, false, 1>(a, max_m, num_cus, s); return; }
+        a.tile_counter = a_in.tile_counter;
+    }
 #ifdef MMEE_DIAG
     static const int order_env = diag_env_int("MMEE_GEMM_ORDER", -1);      // A/B of the queue order: 0 / 1 for every GEMM, 2 = N fastest where N <= 768
     if (order_env == 0 || order_env == 1) a.tile_order = order_env;
     else if (order_env == 2) a.tile_order = a.N <= 768 ? 1 : 0;
+    else if (order_env == 3 || order_env == 4) a.tile_order = a.N >= 2304 ? order_env - 1 : a.tile_order;      // round 6: W-stationary (3) / A-panel (4) order for the wide GEMMs
     static const int forced = diag_env_int("MMEE_SPLIT_CFG", 0);      // 1 = CfgA, 2 = CfgB, 0 / 3 = CfgC
     const bool use_a = forced == 1;
     if (a.dbg_noload && (forced == 0 || forced == 3)) {      // timing diagnostics of the default configuration (tools/gemm_split_shapes.py)

@@ -339,6 +339,40 @@ __global__ __launch_bounds__(Cfg::THREADS, 4) void gemm_split_kernel(const GemmA
                 __syncthreads();
                 const int j = *q_slot;
                 __syncthreads();
+                if (g.tile_order >= 2) {
+                    // Round 6 experiments (profiles/r06_gemm_xcd_schedules.txt).  Orders 0 / 1 walk ONE group of GM M-tiles through
+                    // all N-tiles before the queue moves to its next group: the 32 CUs of an XCD run GM M-tiles x 4 N-tiles at a time, the next 32
+                    // entries keep the A panels (GM x 256 rows x K: 6.3 MB at K = 768, more than the 4 MB L2) and change the W tiles -- both are
+                    // refetched.  tile_order 2, W-STATIONARY: the queue keeps a block of CW = 4 N-tiles (3 MB of W at K = 768) and sweeps ALL of
+                    // its M-groups under it before it takes the next block: W stays in the XCD's L2, only A streams.  tile_order 3, the verdict's
+                    // A-PANEL order: one 256-row A panel (0.77 MB) at a time through all its N-tiles (GM = 1, N fastest).
+                    const int gq = q < n_groups ? (n_groups - q + 7) / 8 : 0;      // M-groups this queue owns: q, q + 8, ...
+                    if (g.tile_order == 2) {
+                        constexpr int CW = 4;
+                        const int nfull = tiles_n / CW, per_cb = gq * GM * CW;
+                        int cb, jj, w;
+                        if (per_cb > 0 && j < nfull * per_cb) { cb = j / per_cb; jj = j - cb * per_cb; w = CW; }
+                        else { cb = nfull; jj = j - nfull * per_cb; w = tiles_n - CW * nfull; }
+                        if (w > 0 && jj < gq * GM * w) {
+                            const int gl2 = jj / (GM * w), r2 = jj - gl2 * GM * w;
+                            tn = cb * CW + r2 / GM;
+                            tm = (q + 8 * gl2) * GM + (r2 - (r2 / GM) * GM);
+                            if (tm < tiles_m) return true;
+                            continue;
+                        }
+                    } else {
+                        const int per_q = gq * GM * tiles_n;
+                        if (j < per_q) {
+                            const int pl = j / tiles_n;                            // this queue's pl-th A panel
+                            tn = j - pl * tiles_n;
+                            tm = (q + 8 * (pl / GM)) * GM + (pl - (pl / GM) * GM);
+                            if (tm < tiles_m) return true;
+                            continue;
+                        }
+                    }
+                    ++q_try;
+                    continue;
+                }
                 const int per_group = GM * tiles_n;
                 const int gl = j / per_group, r = j - gl * per_group;
                 const int grp = q + 8 * gl;

@@ -432,6 +432,12 @@ struct AttnArgs {
                                      // numbering; null: doc_off
     int q_limit;                     // > 0: only queries < q_limit of every document (the CLS probe asks for the first block)
     int terms;                       // attention_idx.hip: 1 = one f16 MFMA term per product (MMEE_FLAG_ONE_TERM); else three
+    // round 6, the 16-bit pair index (attention_idx.hip, IDX16): pair_idx then holds two bytes (4 bx, 4 by) per pair, idx_doc_stride counts dwords
+    int idx16;
+    const unsigned char* lut1;       // [n1] 1-D bucket of delta + c1 (the delta table of a head is w1[head][lut1[.]])
+    int n_visual;                    // visual rows at the end of every document (row j of a document: token j, then patch j - n_text)
+    const unsigned* keymask;         // [orig doc][idx_nb]: bit j <-> key 32 kb + j masked (past the document, pad row, hole)
+    const int* doc_flags;            // [orig doc]: != 0 when a key INSIDE the document is masked (rare: MMEE_FLAG_DENSE_ROWS, holes)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -450,6 +456,10 @@ void launch_attention_f32(const AttnArgs& a, int max_docs, int num_cus, hipStrea
 unsigned long long* attention_pair_stamps();
 unsigned long long* attention_idx_stamps();
 bool attention_idx_supports(const AttnArgs& a);
+bool attention_idx16_fits(int bins1, int bins2, int n1);
+void launch_pair_index16(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1, int n1,
+                         const unsigned char* lut2, int c2, int n2, int bins1, unsigned* out16, size_t doc_stride16, unsigned* out_q0,
+                         unsigned* keymask, int* doc_flags, int max_len, hipStream_t s);
 void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStream_t s);
 void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int nb, const unsigned char* lut1, int c1, int n1,
                        const unsigned char* lut2, int c2, int n2, int bins1, unsigned* out, size_t doc_stride, int max_len, hipStream_t s);

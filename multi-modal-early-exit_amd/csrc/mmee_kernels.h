@@ -147,6 +147,8 @@ void launch_patch_mean(const float* X, int H, const int* x_phys, const int* doc_
                        int max_docs, hipStream_t s);
 void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s);
 void launch_decide(const DecideArgs& a, hipStream_t s);
+void launch_pack_results(const float* logits, const int* exit_layer, const float* conf, int n, int K, int* rows, hipStream_t s);
+void launch_unpack_results(const int* rows, int n, int K, float* logits, int* exit_layer, float* conf, hipStream_t s);
 void launch_compact_rows(const StageCounts* n_counts, const int* n_doc_off, const int* n_x_src, const int* n_meta_src,
                          const RowMeta* meta_old, RowMeta* meta_new, int* row_src, int max_docs, int num_cus, hipStream_t s);
 // out[doc_orig ? doc_orig[i] : i] = CLS row of active document i; split_inv != 0: X holds split-f16 rows scaled by 1 / split_inv

@@ -1,7 +1,8 @@
 // Document preparation, text / visual embedding rows, mean-pool exits' inputs and the row LayerNorm.
 //
-//   doc_prep / doc_scan / row_meta : the packed ("ragged") row layout.  A document contributes its valid text rows
-//       (attention_mask != 0; row 0 = CLS always) followed by its 197 visual rows.  Pad rows never enter the encoder:
+//   doc_prep / doc_scan / row_meta : the packed ("ragged") row layout.  A document contributes its text rows up to the LAST position
+//       the attention mask keeps (row 0 = CLS always; a masked position before that one stays a row, masked as a key) followed by its
+//       197 visual rows.  Trailing pad rows never enter the encoder:
 //       they are masked as keys (EE/models/LayoutLMv3.py:622-624) and no encoder-level exit reads them
 //       (:226 takes hidden[:,0,:]), so dropping them changes no observable output.  MMEE_FLAG_DENSE_ROWS keeps them.
 //   embed_text   : A2 = LayoutLMv3TextEmbeddings.forward (HF:160-199, spatial concat HF:112-136) + the model-level
@@ -23,12 +24,29 @@ __global__ __launch_bounds__(256) void doc_prep_kernel(PrepArgs a) {
     const int ept = (T + 255) / 256;
     const int j0 = tid * ept;
     int kept_cnt = 0, np_cnt = 0, bad = 0;
+    // Round 6: the kept text rows of a document are a PREFIX of its tokens -- everything up to the last position the mask keeps (row 0 = CLS
+    // always).  A masked position INSIDE that prefix (a hole in the mask; the tokenizer never makes one, but the signature allows it) stays a
+    // row, masked as a key exactly as under MMEE_FLAG_DENSE_ROWS, so that row j of a document is token j and the 1-D relative position of a
+    // key tile is "tile base + lane constant" (attention_idx.hip, IDX16).  Trailing pad rows are dropped as before.
+    int last = 0;
+    for (int e = 0; e < ept; ++e) {
+        const int j = j0 + e;
+        if (j < T && a.attention_mask && a.attention_mask[(size_t)b * T + j] != 0) last = j;
+    }
+    if (!a.attention_mask) last = T - 1;
+    s_kept[tid] = last;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_kept[tid] = s_kept[tid] > s_kept[tid + o] ? s_kept[tid] : s_kept[tid + o];
+        __syncthreads();
+    }
+    const int last_kept = s_kept[0];
+    __syncthreads();
     for (int e = 0; e < ept; ++e) {
         const int j = j0 + e;
         if (j < T) {
             const long long id = a.input_ids[(size_t)b * T + j];
-            const bool valid = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0) : true;
-            kept_cnt += (a.dense_rows || valid || j == 0) ? 1 : 0;
+            kept_cnt += (a.dense_rows || j <= last_kept) ? 1 : 0;
             np_cnt += (id != a.pad_id) ? 1 : 0;
             bad |= (id < 0 || id >= a.vocab) ? 1 : 0;
             if (a.token_type_ids) {
@@ -59,8 +77,7 @@ __global__ __launch_bounds__(256) void doc_prep_kernel(PrepArgs a) {
         const int j = j0 + e;
         if (j < T) {
             const long long id = a.input_ids[(size_t)b * T + j];
-            const bool valid = a.attention_mask ? (a.attention_mask[(size_t)b * T + j] != 0) : true;
-            const bool kept = a.dense_rows || valid || j == 0;
+            const bool kept = a.dense_rows || j <= last_kept;
             a.text_dst[(size_t)b * T + j] = kept ? kbase : -1;
             kbase += kept ? 1 : 0;
             int pid;

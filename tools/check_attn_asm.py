@@ -4,7 +4,7 @@
 
 attention_idx.hip issues two kinds of vector loads as inline asm so that hipcc places no `s_waitcnt vmcnt(0)` of its own beside the
 pending LDS-DMA pieces: the PAIR-INDEX words of a key tile (four `global_load_dwordx4` with a scalar base, 16 registers carried around
-the tile loop) and the Q fragments of an item (eight `global_load_dwordx4 ... off`, 32 registers).  Their destination registers only
+the tile loop; two loads / 8 registers in the IDX = 16 instantiations of round 6) and the Q fragments of an item (eight `global_load_dwordx4 ... off`, 32 registers).  Their destination registers only
 become valid at a hand-placed counted wait.  hipcc does not know the loads are pending, so a register copy, spill, move to an AGPR or
 re-definition that it inserts between the load and that wait would silently read or clobber data in flight (seen once for the index
 words: a v_mov in front of the wait).  This script compiles the file to assembly WITH THE MAKEFILE'S FLAGS (`make print-flags`) and, for
@@ -134,8 +134,9 @@ def main():
             for k in range(len(ins)):
                 if is_idx[k]:
                     idx |= dest(k)
-            if len(idx) != 16:
-                print(f"{name}: the index loads write {len(idx)} registers, not one set of 16: a copy would be needed on some path")
+            want = 8 if name.endswith("ELi16EEEvNS_8AttnArgsEPyi") else 16      # IDX = 16 (round 6): two loads per tile, eight registers
+            if len(idx) != want:
+                print(f"{name}: the index loads write {len(idx)} registers, not one set of {want}: a copy would be needed on some path")
                 bad += 1
                 continue
             ends = [k for k in range(len(ins)) if is_idx[k] and not (k + 1 < len(ins) and is_idx[k + 1])]
