@@ -957,11 +957,13 @@ void launch_attention_idx(const AttnArgs& a, int max_docs, int num_cus, hipStrea
         }
     }
 #endif
-    if (a.pair_idx && a.idx16) {         // round 6: 16-bit pair index + delta table (the default wherever the handle's shapes allow it)
+#ifdef MMEE_DIAG
+    if (a.pair_idx && a.idx16) {         // round 6 experiment (diagnostic library, MMEE_ATTN_IDX=16): 16-bit pair index + delta table
         if (a.terms == 1 && !stamps && !dbg) launch_idx<true, kXP, 1, 16>(a, max_docs, num_cus, nullptr, 0, s);      // MMEE_FLAG_ONE_TERM
         else launch_idx<true, kXP, 3, 16>(a, max_docs, num_cus, stamps, dbg, s);
         return;
     }
+#endif
     if (a.terms == 1 && a.pair_idx && !stamps && !dbg) { launch_idx<true, kXP, 1>(a, max_docs, num_cus, nullptr, 0, s); return; }      // MMEE_FLAG_ONE_TERM
     if (a.pair_idx) launch_idx<true, kXP>(a, max_docs, num_cus, stamps, dbg, s);
     else launch_idx<false, (kXP & ~2)>(a, max_docs, num_cus, stamps, dbg, s);      // no bias to put first

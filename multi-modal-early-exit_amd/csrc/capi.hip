@@ -552,7 +552,10 @@ int ee_create(const ee_config* c, ee_handle** out) {
             if (!beit) {
                 h->idx_nb = (int)((Tm + Pv + 31) / 32);
                 const int maxpos = (int)std::max(Tm, Pv);
-                static const int idx_env = mmee::diag_env_int("MMEE_ATTN_IDX", 16);      // diagnostic library only: 32 = the round-2..5 word index (A/B)
+                // Round 6: the 16-bit pair index + delta table (attention_idx.hip, IDX16) is bit-identical to the word index and its lookups are 13 %
+                // cheaper, but the 4 KB delta table it refills per work item costs more than that returns (9.27 against 9.15 ms per forward of 256
+                // documents): measured, not shipped.  MMEE_ATTN_IDX=16 selects it in the DIAGNOSTIC library (A/B, tests of the form).
+                static const int idx_env = mmee::diag_env_int("MMEE_ATTN_IDX", 32);
                 h->idx16 = idx_env == 16 && mmee::attention_idx16_fits(c->rel_pos_bins, c->rel_2d_pos_bins, 2 * maxpos - 1);
                 h->idx_stride = (size_t)h->idx_nb * h->idx_nb * (h->idx16 ? 512 : 1024);
                 rc |= dev_alloc(h, &h->pair_idx, Bm * h->idx_stride);
@@ -771,6 +774,13 @@ int ee_finalize(ee_handle* h) {
 
 namespace {
 
+__global__ void zero_words_kernel(int* __restrict__ a, int na, int* __restrict__ b, int nb) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0;
+        else b[i - na] = 0;
+    }
+}
+
 __global__ void set_thresholds_kernel(ThrPack p, double* __restrict__ dst) {
     for (int i = threadIdx.x; i < p.n; i += blockDim.x) dst[i] = p.v[i];
 }
@@ -866,8 +876,9 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
         return fail(h, "ee_graph_capture: the one-shot side inputs / outputs (inputs_embeds, hidden states, head mask, attention maps) and ee_profile "
                        "belong to eager calls");
     if (!cap) { const int rc_pre = forward_pre(h, s); if (rc_pre) return rc_pre; }
-    HIP_OK(h, hipMemsetAsync(h->err_flag, 0, 16, s));
-    HIP_OK(h, hipMemsetAsync(h->queue_heads, 0, sizeof(int) * (size_t)h->n_queue_heads, s));
+    // (a kernel, not hipMemsetAsync: the same launch list then serves the eager call and the captured graph -- replays whose memset NODES were
+    //  preceded by an eager forward on the handle came back with an unzeroed error word on ROCm 7.2, tools/graph_debug2.py)
+    hipLaunchKernelGGL(zero_words_kernel, dim3(32), dim3(256), 0, s, h->err_flag, 4, h->queue_heads, h->n_queue_heads);
     h->next_queue_head = 0;
     auto next_head = [&]() -> int* {                      // 8 XCD-local counters x 16 ints (one 64-byte line each)
         if (h->next_queue_head + 128 > h->n_queue_heads) return nullptr;

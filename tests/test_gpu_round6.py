@@ -188,3 +188,56 @@ def test_result_rows_of_the_c_abi_equal_the_python_hosts(pkg):
     assert torch.equal(lg2.view(torch.int32), lg.view(torch.int32)) and torch.equal(ex2, ex) and torch.equal(cf2, cf)
     a, b, c = pkg.dist.unpack_results(rows)
     assert torch.equal(a.view(torch.int32), lg.view(torch.int32)) and torch.equal(b, ex) and torch.equal(c, cf)
+
+
+def test_holes_in_the_attention_mask_stay_rows(pkg, oracle):
+    """Round 6: the kept text rows of a document are a PREFIX of its tokens (csrc/prep_embed.hip): a masked position before the last kept one --
+    which the tokenizer never produces but the reference's signature accepts -- stays a row and is masked as a key, exactly as under dense rows.
+    Both layouts, both schedules, against the oracle (which masks keys as the reference does, EE/models/LayoutLMv3.py:622-624)."""
+    import torch
+    from .conftest import H256_KW
+    ee = dict(exits=["text_visual_concat", 1, 2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
+    W = pkg.synth.make_weights(cfg, seed=21, head_gain=6.0)
+    docs = pkg.synth.make_documents(cfg, 6, seed=22, text_len=64, min_words=20)
+    rng = np.random.default_rng(5)
+    am = docs["attention_mask"]
+    for b in range(6):                                   # punch holes into the valid range (never position 0), one document masked almost entirely
+        n = int(am[b].sum())
+        holes = rng.choice(np.arange(1, n - 1), size=(n - 3) if b == 5 else max(1, n // 4), replace=False)
+        am[b, holes] = 0
+    ref = oracle.forward_all(cfg, W, docs, ee["exits"], strategy="ramp")
+    eng = pkg.EarlyExitEngine(cfg, max_docs=6, max_text_len=64)
+    eng.load_weights(W)
+    t = {k: torch.from_numpy(docs[k]).cuda() for k in ("input_ids", "attention_mask", "bbox", "pixel_values")}
+    for kw in (dict(), dict(dense_rows=True), dict(whole_layers=True), dict(xprobe=False)):
+        out = eng.forward(**t, dump_all=True, want_all=True, validate=True, **kw)
+        np.testing.assert_allclose(_np(out.all_logits).astype(np.float64), ref["logits_store"], rtol=0, atol=1e-4)
+    rows = eng.stage_counts()["rows"][0]
+    last = [int(np.nonzero(am[b])[0].max()) + 1 for b in range(6)]
+    assert rows == sum(last) + 6 * 17                     # prefix up to the last kept token + (64 / 16)^2 + 1 visual rows per document
+    conf = np.sort(_np(out.all_crit)[1])
+    thr = [2.0, float(0.5 * (conf[2] + conf[3])), 2.0, 2.0]
+    a, b = eng.forward(**t, thresholds=thr, xprobe=False), eng.forward(**t, thresholds=thr, xprobe=False, dense_rows=True)
+    assert np.array_equal(_np(a.exit_layer), _np(b.exit_layer)) and len(np.unique(_np(a.exit_layer))) == 2
+    eng.close()
+
+
+def test_idx16_attention_form_is_bit_identical_to_the_word_index(pkg):
+    """Round 6 experiment kept in the DIAGNOSTIC library (MMEE_ATTN_IDX=16): the 16-bit pair index + delta table form of the attention kernel
+    returns the bits of the shipped 32-bit form (tools/attn_xp_check.py: 24 base-shape documents through every layer)."""
+    import os
+    import subprocess
+    import sys
+    from .conftest import ROOT
+    diag = os.path.join(ROOT, "multi-modal-early-exit_amd", "libmmee_hip_diag.so")
+    if not os.path.exists(diag):
+        pytest.skip("diagnostic library not built (make -C multi-modal-early-exit_amd/csrc diag)")
+    tool = os.path.join(ROOT, "tools", "attn_xp_check.py")
+    ref = os.path.join("/tmp", f"mmee_idx32_{os.getpid()}.pt")
+    env = dict(os.environ, MMEE_LIB=diag)
+    r = subprocess.run([sys.executable, tool, "save", ref], env=dict(env, MMEE_ATTN_IDX="32"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, tool, "cmp", ref], env=dict(env, MMEE_ATTN_IDX="16"), capture_output=True, text=True, timeout=600)
+    os.remove(ref)
+    assert r.returncode == 0 and "0.000e+00" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
