@@ -690,7 +690,7 @@ def main(argv=None):
     out0 = out if (len(batches) == 1 or stub) else step(i=0)      # batch 0's results: the documents the CPU baseline re-computes
     # rounds 1-5's headline, kept beside the new one: every step re-runs ONE resident batch (batch 0)
     resident_rate = None
-    if world == 1 and len(batches) > 1 and not stub and not strong:
+    if world == 1 and len(batches) > 1 and not stub and not strong and not a.thresholds:
         step(i=0); sync()
         t1 = time.perf_counter()
         for _ in range(a.steps):

@@ -10,9 +10,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # thresholds AND the exit-layer schedule pinned: every forward of every pass is the same launch sequence
 PLAN=${PLAN:-1,3,5,7,9}
+# --distinct-batches 1: every forward of every pass runs resident batch 0, the batch of the bench line's own HIP-event step (the roofline's launches), so that the
+# per-kernel averages here are averages over IDENTICAL launches and must agree with the line's avg_launch_ms
 # --serial-slices: the two micro-batches one after the other on one stream, so that every kernel's start-to-end time is its own (with two
 # streams a small kernel's duration includes its wait for the other stream's kernel and the per-kernel times stop adding up to the step)
-COMMON="--cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --serial-slices --thresholds $THR --probe-layers $PLAN"
+COMMON="--cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --serial-slices --distinct-batches 1 --no-small-batch --thresholds $THR --probe-layers $PLAN"
 rm -rf $OUT/${TAG}_stats && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o t -- python3 $ROOT/bench.py --steps 8 --warmup 1 $COMMON > $OUT/${TAG}_stats.log 2>&1
 cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 i=0

@@ -9,7 +9,7 @@ ROOT=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/${TAG}_kt
-rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_kt -o t -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --serial-slices --thresholds $THR --probe-layers ${PLAN:-1,3,5,7,9} $EXTRA > $OUT/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_kt -o t -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-docs 0 --stream-docs 0 --no-traffic --no-profile --serial-slices --distinct-batches 1 --no-small-batch --thresholds $THR --probe-layers ${PLAN:-1,3,5,7,9} $EXTRA > $OUT/${TAG}_kt.log 2>&1
 python3 - "$(find $OUT/${TAG}_kt -name '*kernel_trace.csv' | head -1)" $OUT/${TAG}_trace.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
