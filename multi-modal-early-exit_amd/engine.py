@@ -197,6 +197,7 @@ class EarlyExitEngine:
             raise capi.MMEEError("load_weights() has not been called")
         R = self.cfg.input_size
         px = self._dev(pixel_values, torch.float32, "pixel_values")
+        emb = None
         if self.beit:                                   # image-only: (B,3,R,R) is the whole input
             if inputs_embeds is not None:
                 raise ValueError("inputs_embeds: an image-only model has no text embeddings")
@@ -205,7 +206,6 @@ class EarlyExitEngine:
             if tuple(px.shape) != (B, self.cfg.num_channels, R, R):
                 raise ValueError(f"pixel_values must be (B,{self.cfg.num_channels},{R},{R})")
         else:
-            emb = None
             if inputs_embeds is not None:
                 # EE/models/LayoutLMv3.py:414-417 -> HF:160-199: the rows replace word_embeddings(input_ids).  Without input_ids the position
                 # ids are the sequential ones of HF:148-158 (nothing says which position is padding); the C-ABI still wants token ids for
@@ -326,7 +326,7 @@ class EarlyExitEngine:
             return CapturedForward(self, gid.value, {k: v for k, v in ins.items() if v is not None}, res)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            if not self.beit and emb is not None:
+            if emb is not None:
                 capi.check(self.lib.ee_set_inputs_embeds(self._h, p(emb)), self._h, "ee_set_inputs_embeds")
             if hs is not None:
                 capi.check(self.lib.ee_set_hidden_states_out(self._h, p(hs)), self._h, "ee_set_hidden_states_out")
@@ -338,7 +338,7 @@ class EarlyExitEngine:
                                      p(out_logits), p(out_exit), p(out_conf), p(all_logits), p(all_crit),
                                      p(head_logits), p(head_crit), p(hidden), stream)
         capi.check(rc, self._h, "ee_forward")
-        self._keepalive = (ids, am, bb, px, tt, ps, None if self.beit else emb, hm)   # borrowed by the enqueued kernels until the stream drains
+        self._keepalive = (ids, am, bb, px, tt, ps, emb, hm)   # borrowed by the enqueued kernels until the stream drains
         if validate:
             self.stage_counts()                        # synchronises; raises on out-of-range inputs
         return EngineOutput(out_logits, out_exit, out_conf, all_logits, all_crit, head_logits, head_crit, hidden, hs, att)

@@ -241,3 +241,21 @@ def test_idx16_attention_form_is_bit_identical_to_the_word_index(pkg):
     r = subprocess.run([sys.executable, tool, "cmp", ref], env=dict(env, MMEE_ATTN_IDX="16"), capture_output=True, text=True, timeout=600)
     os.remove(ref)
     assert r.returncode == 0 and "0.000e+00" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_captured_graph_of_the_image_only_model(pkg):
+    """``capture()`` on a BEiT / DiT handle (pixel_values is the whole input): replays equal the eager call, thresholds per launch."""
+    import torch
+    g = load_golden("dit_tiny")
+    cfg = pkg.ModelConfig.dit_tiny(EE_config=DIT_EE)
+    eng = pkg.EarlyExitEngine(cfg, max_docs=8, max_text_len=0)
+    eng.load_weights(pkg.synth.make_weights_beit(cfg, seed=int(g["seed_w"])))
+    pix = torch.from_numpy(pkg.synth.make_documents(cfg, 6, seed=int(g["seed_docs"]), text_len=8)["pixel_values"]).cuda()
+    cap = eng.capture(pixel_values=pix.clone(), thresholds=2.0)
+    for thr in (float(g["pol_thr1"]), 2.0, 0.0):
+        e = eng.forward(pixel_values=pix, thresholds=thr)
+        o = cap.launch(thresholds=thr, validate=True)
+        assert np.array_equal(_np(o.exit_layer), _np(e.exit_layer)) and np.array_equal(_np(o.logits), _np(e.logits))
+    assert np.array_equal(_np(cap.launch(thresholds=float(g["pol_thr1"])).exit_layer), g["pol_exits1"])
+    cap.close()
+    eng.close()
