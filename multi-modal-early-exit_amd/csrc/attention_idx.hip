@@ -321,6 +321,12 @@ enum { V_HOT = 0, V_TAIL = 1, V_PENULT = 2, V_LAST = 3 };
 // The "16.8 % of a wave's time is serial per-item work" of round 4 is a per-WAVE share: with three workgroups per CU the SIMD issues other
 // waves meanwhile, so what bounds the kernel is instruction issue (VALU 48 %, matrix pipe 40 % of the cycles), not the item prologue.
 // Removed; the kernel below is the round-4 form.
+// Round 6 (profiles/r06_attention_conflicts_and_idx16.txt): (1) the IDX = 16 form below (16-bit pair index + 1-D bias from a delta table at immediate offsets):
+// bit-identical, lookups -13 %, kernel -1.3 % because of its per-item table -- diagnostic library only.  (2) One ticket per (document, head), the
+// workgroup walking its query tiles itself (ticket, table fill and head set-up paid once per (document, head)): bit-identical, 11.2 against 9.3 ms at 256
+// documents and 41.6 against 36.9 ms at 1024 (16 tickets per workgroup slot, so not a balance effect: the four query tiles of a (document, head) then stream
+// its K / V rows one after the other instead of side by side on four workgroups that share every L2 fill); with it the IDX = 16 form is the faster of the
+// two (11.1 / 40.9 ms: its table is amortised) and both lose to the shipped form.  Removed.
 constexpr int kXP = 2 | 16;
 // TERMS = 1 (MMEE_FLAG_ONE_TERM, a reported low-precision mode, never a parity path): both products on the hi planes only.
 // IDX = 16 (round 6): the 16-bit pair index + the 1-D bias as a DELTA table read at "tile base + immediate" (header of pair_index16_kernel):

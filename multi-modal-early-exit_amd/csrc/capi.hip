@@ -945,10 +945,12 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
         launch_prep(pa, s);
         if (h->pair_idx && use_idx) {    // bucket indices of every (query, key) pair, once per forward: shared by all heads and layers
             ProfScope pi(h, P_PAIRIDX, s);
+#ifdef MMEE_DIAG
             if (h->idx16)
                 mmee::launch_pair_index16(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
                                           h->pair_idx, h->idx_stride, h->pair_idx0, h->keymask, h->doc_flags, max_len, s);
             else
+#endif
                 mmee::launch_pair_index(h->meta[0], S_doc_off(0), B, h->idx_nb, h->lut1_dev, h->c1, h->n1, h->lut2_dev, h->c2, h->n2, c.rel_pos_bins,
                                         h->pair_idx, h->idx_stride, max_len, s);
         }
