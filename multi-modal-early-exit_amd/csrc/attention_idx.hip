@@ -157,6 +157,7 @@ void launch_pair_index(const RowMeta* meta, const int* doc_off, int n_docs, int 
                        doc_stride, max_len);
 }
 
+#ifdef MMEE_DIAG      // the IDX16 form is an experiment of the diagnostic library (measured -1.3 %, not shipped): the release library holds none of it
 // ---------------------------------------------------------------------------------------------------------------
 // Round 6, the 16-bit pair index (IDX16).  The 1-D bucket of a pair depends on pos_k - pos_q alone, and since the kept text rows of a document
 // are a prefix of its tokens (prep_embed.hip) row j of a document IS token j (visual row j: patch j - n_text): inside a key tile the
@@ -262,6 +263,7 @@ void launch_pair_index16(const RowMeta* meta, const int* doc_off, int n_docs, in
     hipLaunchKernelGGL(pair_index16_kernel, dim3(n_docs * nb), dim3(256), lds, s, meta, doc_off, n_docs, nb, lut1, c1, n1, lut2, c2, n2, bins1, out16,
                        doc_stride16, out_q0, keymask, doc_flags, max_len);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // The attention kernel.  MODE = 0 the path's kernel; 1 stamped diagnostic build (phase sums go to `stamps`, a buffer nothing else reads;
