@@ -134,7 +134,7 @@ def main():
             for k in range(len(ins)):
                 if is_idx[k]:
                     idx |= dest(k)
-            want = 8 if re.search(r"ELi16ELb[01]EEEvNS_8AttnArgsEPyi$", name) else 16      # IDX = 16 (round 6): two loads per tile, eight registers
+            want = 8 if re.search(r"ELi16(ELb[01])?EEEvNS_8AttnArgsEPyi$", name) else 16      # IDX = 16 (round 6): two loads per tile, eight registers
             if len(idx) != want:
                 print(f"{name}: the index loads write {len(idx)} registers, not one set of {want}: a copy would be needed on some path")
                 bad += 1
