@@ -1334,7 +1334,14 @@ int forward_body(ee_handle* h, const int64_t* input_ids, const int64_t* attentio
                 launch_gemm_split(g, EPI_RESID, B, cus, s);
                 launch_ln_rows(h->Xc, nullptr, nullptr, nd, B, H, w.f_g, w.f_beta, c.layer_norm_eps, cus, s, h->Xcs, mmee::kSplitScaleX, h->err_flag);
             }
-            launch_gather_cls(h->Xcs, H, h->iota, nullptr, nd, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
+            // the f32 copy of the CLS rows is read by a head WITHOUT a dense layer on the split kernel only (one-layer heads): the others take Xcs
+            {
+                const bool fin = l == L - 1 && !(next_enc < c.n_encoder_exits && c.encoder_exit_layers[next_enc] == L);
+                const HeadW* hw0 = fin ? &h->classifier : &h->enc_heads[next_enc];
+                const bool gate = !fin && c.strategy == MMEE_STRATEGY_GATE;
+                const bool dense_ok = hw0->dense_w && hw0->dense_s && (!gate || (h->classifier.dense_w && h->classifier.dense_s));
+                if (!dense_ok) launch_gather_cls(h->Xcs, H, h->iota, nullptr, nd, h->cls_f32, B, s, 1.0f / mmee::kSplitScaleX);
+            }
             h->layer_probe_stage[l] = cur;
         };
 

@@ -18,10 +18,11 @@ namespace mmee {
 // ---------------------------------------------------------------------------------------------------------------
 // out[i][c] = <in[row(i)], W[c]> + b[c]; one wave per document
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs a) {
+template <int WAVES>
+__device__ __forceinline__ void head_out_body(const HeadOutArgs& a) {
     const int n = *a.n_docs_ptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    for (int i = blockIdx.x * WAVES + wave; i < n; i += gridDim.x * WAVES) {
         const int row = a.gather ? a.gather[i] : i;
         const float* x = a.in + (size_t)row * a.ld;
         f32x4 xv[kMaxNV];
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(256) void head_out_kernel(HeadOutArgs a) { head_out_body<4>(a); }
 
 void launch_head_out(const HeadOutArgs& a, int max_docs, hipStream_t s) {
     int grid = (max_docs + 3) / 4;
@@ -100,7 +103,7 @@ __device__ inline double crit_f64(const float* z, int K, double temp, int criter
 //   survivors: wave ballot -> popcount prefix -> cross-wave prefix in LDS -> running carry = new dense index,
 //   and the same scan over row counts = new dense row offset.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
+__device__ __forceinline__ void exit_decide_body(const DecideArgs& a) {
     __shared__ int s_cnt[16], s_rows[16];
     __shared__ unsigned long long s_sq[16];
     __shared__ int s_carry_docs, s_carry_rows;
@@ -184,9 +187,15 @@ __global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) {
     }
 }
 
+__global__ __launch_bounds__(1024) void exit_decide_kernel(DecideArgs a) { exit_decide_body(a); }
+
 void launch_decide(const DecideArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(exit_decide_kernel, dim3(1), dim3(1024), 0, s, a);
 }
+
+// Round 6: the head's output projection and the decision were built as ONE launch (every workgroup writes its documents' logits, fences,
+// takes a ticket; the last arrival runs the scan: nobody waits, same bits, 91 GPU tests green) and measured on config 3 (2 x 512 documents, 48 exits per step):
+// 52.7 us per exit against 31 + 16 us for the two launches -- the fences and the serial scan behind the last arrival cost what the launch saved.  Removed.
 
 // new dense row r of surviving document k  <-  physical X row n_x_src[k] + t, metadata row n_meta_src[k] + t
 __global__ __launch_bounds__(256) void compact_rows_kernel(const StageCounts* n_counts, const int* __restrict__ n_doc_off,
