@@ -352,7 +352,8 @@ class EarlyExitEngine:
         rewritten by every ``captured.launch(thresholds=..., temperatures=...)``.  Thresholds and temperatures are arguments of the launch,
         everything else ((B, T), flags, which optional outputs exist, the pinned exit-layer schedule) is part of the capture.  For the
         reference's operating point (eval_batch_size = 1, EE/configs.py:36; EE/utils.py:169-193): ~185 kernel launches per forward become
-        one graph launch.  Replays return the bits of the eager call on the same inputs."""
+        one graph launch.  Replays return the bits of the eager call on the same inputs.  Device tensors of the right dtype are BORROWED as they are
+        (no copy, as in ``forward``): hand in clones when the caller's own tensors must not become the graph's buffers."""
         return self.forward(*args, _capture=True, **kw)
 
     def check(self):
