@@ -408,6 +408,7 @@ class EarlyExitEngine:
         pinned list (None for the default).  The mask is part of the handle's state until changed."""
         if probe_layers is False:
             capi.check(self.lib.ee_set_probe_mask(self._h, 0, 0), self._h, "ee_set_probe_mask")
+            self._pinned = False
             return None
         if probe_layers is None:
             xp = self.xprobe_default if xprobe is None else bool(xprobe)
@@ -422,6 +423,7 @@ class EarlyExitEngine:
         for l in layers:
             mask |= 1 << l
         capi.check(self.lib.ee_set_probe_mask(self._h, 1, mask), self._h, "ee_set_probe_mask")
+        self._pinned = True
         return layers
 
     def set_criterion(self, strategy):

@@ -173,6 +173,7 @@ class MicroBatchedEngine:
         out = None
         for e in self.engines:
             out = e.pin_schedule(probe_layers)
+        self._pinned = probe_layers is not False
         return out
 
     def set_criterion(self, strategy):

@@ -87,6 +87,11 @@ class LayoutLMv3EEForSequenceClassification:
         workspace).  ``output_hidden_states=True`` is a per-handle feature and runs on the first handle, a slice at a time."""
         if not isinstance(config, ModelConfig):
             config = ModelConfig.from_hf_dict(dict(config))
+        else:
+            # the model owns its configuration: _sync_exit_config writes the criterion override into EE_config, which must not be the CALLER's dictionary
+            # (round 6: a test's override leaked into the module-level dictionary another test built its model from)
+            import dataclasses
+            config = dataclasses.replace(config, EE_config=dict(config.EE_config))
         self.model_config = config
         if micro_batches > 1:
             from .microbatch import MicroBatchedEngine
@@ -260,9 +265,25 @@ class LayoutLMv3EEForSequenceClassification:
         ``thresholds`` defaults to ``config.exit_config["global_threshold"]``."""
         if thresholds is None:
             thresholds = self.config.exit_config["global_threshold"]
+        self._small_batch_schedule(pixel_values, kw)
         return self._run(dict(input_ids=input_ids, attention_mask=attention_mask, bbox=bbox, pixel_values=pixel_values,
                               token_type_ids=token_type_ids, position_ids=position_ids),
                          thresholds=thresholds, temperatures=temperatures, **kw)
+
+    SMALL_BATCH_WHOLE_LAYERS = 16
+
+    def _small_batch_schedule(self, pixel_values, kw):
+        """Round 6: a probe in front of an exit layer is 13 launches; at the reference's operating point (``eval_batch_size = 1``, EE/configs.py:36)
+        it never pays -- one document's forward takes 2.5 ms probe-first and 1.95 ms with whole layers, eight documents 5.2 / 4.2 ms, 64 the same
+        (``bench.py`` ``small_batch``).  For batches of at most ``SMALL_BATCH_WHOLE_LAYERS`` documents ``early_exit`` therefore runs whole layers unless the
+        caller chose a schedule (``whole_layers`` / ``probe_always`` / ``xprobe`` arguments, or ``engine.pin_schedule``): a function of the call's batch
+        size, never of timing; exit indices are the same and whole layers are the form whose rows are bit-identical to the dump-all rows."""
+        if pixel_values is None or any(k in kw for k in ("whole_layers", "probe_always", "xprobe")):
+            return
+        if getattr(self.engine, "_pinned", False):
+            return
+        if int(pixel_values.shape[0]) <= self.SMALL_BATCH_WHOLE_LAYERS:
+            kw["whole_layers"] = True
 
 
 class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
@@ -294,4 +315,5 @@ class DiTEEForImageClassification(LayoutLMv3EEForSequenceClassification):
     def early_exit(self, pixel_values=None, thresholds=None, temperatures=None, **kw) -> EngineOutput:
         if thresholds is None:
             thresholds = self.config.exit_config["global_threshold"]
+        self._small_batch_schedule(pixel_values, kw)
         return self._run(dict(pixel_values=pixel_values), thresholds=thresholds, temperatures=temperatures, **kw)

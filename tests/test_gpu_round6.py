@@ -259,3 +259,36 @@ def test_captured_graph_of_the_image_only_model(pkg):
     assert np.array_equal(_np(cap.launch(thresholds=float(g["pol_thr1"])).exit_layer), g["pol_exits1"])
     cap.close()
     eng.close()
+
+
+def test_model_surface_runs_small_batches_whole(pkg):
+    """Round 6: ``model.early_exit`` on a batch of at most 16 documents (the reference's eval_batch_size = 1 included) runs whole layers -- a probe is
+    13 launches and never pays there (bench.py ``small_batch``) -- unless the caller chose a schedule; larger batches keep the default (every decision
+    layer probed first).  Same exits, logits within the bar, and the small-batch form is the one whose rows are bit-identical to the dump-all rows."""
+    import torch
+    from .conftest import H256_KW
+    ee = dict(exits=[1, 2], encoder_layer_strategy="ramp")
+    cfg = pkg.ModelConfig.tiny(EE_config=ee, **H256_KW)
+    m = pkg.LayoutLMv3EEForSequenceClassification(cfg, weights=pkg.synth.make_weights(cfg, seed=9, head_gain=6.0), max_docs=24, max_text_len=48)
+    docs = pkg.synth.make_documents(cfg, 24, seed=10, text_len=48, min_words=3)
+    t = {k: torch.from_numpy(v).cuda() for k, v in docs.items() if k != "labels"}
+    dump = m.forward(**t)
+    conf = np.sort(_np(dump.exit_states[0][1]))
+    thr = [float(0.5 * (conf[11] + conf[12])), 2.0, 2.0]
+    big = m.early_exit(**t, thresholds=thr)
+    plan_big = m.engine.layer_plan()
+    assert sum(plan_big["docs_probe"]) > 0                                   # 24 documents: the default schedule
+    small_t = {k: v[:8] for k, v in t.items()}
+    small = m.early_exit(**small_t, thresholds=thr)
+    assert sum(m.engine.layer_plan()["docs_probe"]) == 0                     # 8 documents: whole layers
+    assert np.array_equal(_np(small.exit_layer), _np(big.exit_layer)[:8])
+    np.testing.assert_allclose(_np(small.logits), _np(big.logits)[:8], rtol=0, atol=1e-4)
+    forced = m.early_exit(**small_t, thresholds=thr, probe_always=True)      # the caller's choice wins
+    assert sum(m.engine.layer_plan()["docs_probe"]) > 0 and np.array_equal(_np(forced.exit_layer), _np(small.exit_layer))
+    m.engine.pin_schedule([0])                                               # ... and so does a pinned schedule
+    m.early_exit(**small_t, thresholds=thr)
+    assert m.engine.layer_plan()["docs_probe"][0] > 0
+    m.engine.pin_schedule(False)
+    m.early_exit(**small_t, thresholds=thr)
+    assert sum(m.engine.layer_plan()["docs_probe"]) == 0
+    m.engine.close()
