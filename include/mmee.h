@@ -28,6 +28,7 @@
 #ifndef MMEE_H
 #define MMEE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

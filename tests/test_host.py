@@ -220,3 +220,19 @@ def test_attention_index_loads_stay_untouched_until_their_wait():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "index-load groups" in r.stdout and "Q-load group" in r.stdout          # both kinds of hand-counted loads were found and checked
     assert "ELb0E" in r.stdout                                                       # ... also in the kernel without a pair index (BEiT / DiT)
+
+
+def test_header_is_plain_c():
+    """include/mmee.h is the drop-in boundary for hosts in ANY language: it must compile as C99 on its own (round 6: it used size_t without <stddef.h>,
+    which only C++ translation units that had already included it got away with)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "mmee.h"\nint main(void) { ee_handle* h = 0; (void)h; return (int)sizeof(ee_config) == 0; }\n')
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
