@@ -439,6 +439,8 @@ struct LnPre {
     float resid_inv;
 };
 template <int NV, bool PRE, bool FULL = false>      // PRE is a separate instantiation: the layers' own LayerNorm launches carry none of its code
+// (Round 6: the wave's NEXT row fetched while the current one is reduced and stored -- 12 more registers, full occupancy kept -- moved the kernel by -1 % (share 4.74 ->
+//  4.69 % of the step) and docs/s by nothing: 7249 / 7229 against 7241 / 7234, tools/lib_ab.sh on one box.  The kernel runs at the memory system's rate; not kept.)
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                       const int* __restrict__ row_src, const int* __restrict__ n_rows_ptr, int H,
                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
